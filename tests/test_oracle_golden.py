@@ -1,0 +1,151 @@
+"""Pins oracle/nerf_oracle.py to the reference: every function of the CPU restatement
+is run on the seeded inputs of tests/golden/cases.py and compared with the outputs the
+unmodified reference produced for them (tests/golden/*.npz, made by make_golden.py).
+
+Same torch CPU kernels, same op order => the comparison is (near) bit-exact; the
+tolerances below only absorb the thread-count dependence of MKL sgemm blocking."""
+import numpy as np
+import torch
+import pytest
+
+import cases
+from oracle import nerf_oracle as O
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+torch.set_grad_enabled(False)
+
+
+def close(a, b, atol=0.0, rtol=0.0):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, equal_nan=True)
+
+
+def test_g1_embed(golden):
+    g, ref = cases.g1_inputs(), golden("g1_embed")
+    assert ref["crc"] == cases.checksum(g["pts"], g["dirs"], g["t"])
+    close(O.embed(T(g["pts"]), 10), ref["pts"])
+    close(O.embed(T(g["dirs"]), 4), ref["dirs"])
+    close(O.embed(T(g["t"]), 10), ref["t"])
+    assert O.embed_dim(10, 3) == 63 and O.embed_dim(4, 3) == 27 and O.embed_dim(10, 1) == 21
+
+
+def test_g2_rays(golden):
+    g, ref = cases.g2_inputs(), golden("g2_rays")
+    st = int(ref["step"][0])
+    o, d = O.get_rays(400, 400, g["K400"], g["c2w400"])
+    close(d.reshape(-1, 3)[::st], ref["d_k"])
+    close(o.reshape(-1, 3)[::st], ref["o_k"])
+    assert o.stride()[:2] == (0, 0)            # stride-0 expand like ray.py:37
+    _, d = O.get_rays(400, 400, g["focal400"], g["c2w400"])
+    close(d.reshape(-1, 3)[::st], ref["d_f"])
+    o, d = O.get_rays(32, 48, g["K_small"], g["c2w_small"])
+    close(d.reshape(-1, 3), ref["d_s"])
+    close(o.reshape(-1, 3), ref["o_s"])
+    on, dn = O.get_rays_np(400, 400, g["K400"], g["c2w400"])
+    assert str(dn.dtype) == str(ref["np_dtype"][0])
+    close(dn.reshape(-1, 3)[::st], ref["d_np"])
+    o, d = O.get_rays(378, 504, g["Kf"], g["c2wf"])
+    close(d.reshape(-1, 3)[::st], ref["d_l"])
+    o2, d2 = O.ndc_rays(378, 504, g["Kf"][0][0], 1., o, d)
+    close(o2.reshape(-1, 3)[::st], ref["o_ndc"])
+    close(d2.reshape(-1, 3)[::st], ref["d_ndc"])
+
+
+def test_g3_coarse(golden):
+    g, ref = cases.g3_inputs(), golden("g3_coarse")
+    o, d = T(g["rays_o"]), T(g["rays_d"])
+    for lindisp in (False, True):
+        for perturb in (0, 1):
+            z = O.coarse_z(T(g["near"]), T(g["far"]), 64, lindisp, T(g["t_rand"]) if perturb else None)
+            pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
+            close(pts[:32], ref[f"pts_l{int(lindisp)}_p{perturb}"])
+
+
+def test_g4_mlp(golden):
+    g, ref = cases.g4_inputs(), golden("g4_mlp")
+    sd_c, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
+    x = T(g["x"])
+    close(O.nerf_mlp(sd_c, x), ref["vanilla"], atol=2e-6, rtol=1e-5)
+    close(O.nerf_mlp(sd_f, x), ref["original"], atol=2e-6, rtol=1e-5)
+    sd_d = O.to_torch_sd(cases.weights_dnerf())
+    for tv in (0.0, 0.5):
+        te = O.embed(torch.full((x.shape[0], 1), tv), 10)
+        out, dx = O.dnerf_mlp(sd_d, x, te)
+        close(out, ref[f"dn_out_t{int(tv*10)}"], atol=2e-6, rtol=1e-5)
+        close(dx, ref[f"dn_dx_t{int(tv*10)}"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("S", [64, 192])
+def test_g5_raw2outputs(golden, S):
+    g, ref = cases.g5_inputs(S), golden(f"g5_raw2outputs_S{S}")
+    for wb in (False, True):
+        r = O.raw2outputs(T(g["raw"]), T(g["z"]), T(g["rays_d"]), 0., wb)
+        for k, v in zip(["rgb", "disp", "acc", "weights", "depth"], r):
+            close(v, ref[f"{k}_w{int(wb)}"])
+    assert np.isnan(ref["disp_w0"][0]) and ref["acc_w0"][0] == 0     # the empty ray
+    r = O.raw2outputs(T(g["raw"]), T(g["z"]), T(g["rays_d"]), 1.0, True, noise=T(g["noise"]) * 1.0)
+    for k, v in zip(["rgb", "disp", "acc", "weights", "depth"], r):
+        close(v, ref[f"{k}_noise"])
+
+
+def test_g6_sample_pdf(golden):
+    g, ref = cases.g6_inputs(), golden("g6_sample_pdf")
+    s_det = O.sample_pdf(T(g["bins"]), T(g["weights"]), 128, det=True)
+    s_rnd = O.sample_pdf(T(g["bins"]), T(g["weights"]), 128, u=T(g["u"]))
+    close(s_det, ref["det"])
+    close(s_rnd, ref["rnd"])
+    close(torch.sort(torch.cat([T(g["z"]), s_det], -1), -1)[0], ref["z_det"])
+    close(torch.std(s_rnd, dim=-1, unbiased=False), ref["std_rnd"])
+
+
+def _rb(g, t=None):
+    return O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), g["near"], g["far"], frame_time=t)
+
+
+def _cmp_dict(ret, ref, keys, atol, rtol=1e-4, nraw=32):
+    for k in keys:
+        v = ret[k]
+        if k in ("raw", "position_delta"):
+            v = v[:nraw]
+        close(v, ref[k], atol=atol, rtol=rtol)
+
+
+def test_g7_static_render_rays(golden):
+    sd_c, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
+    g = cases.g7_inputs()
+    ref = golden("g7_c1")
+    r = O.render_rays(_rb(g), sd_c, None, 64, 0, white_bkgd=True, retraw=True)
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "raw"], atol=2e-6)
+    ref = golden("g7_c2")
+    r = O.render_rays(_rb(g), sd_c, sd_f, 64, 128, white_bkgd=True, retraw=True)
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "raw"], atol=5e-6)
+    gs = cases.g7_inputs(n=256, seed=11)
+    ref = golden("g7_lindisp")
+    r = O.render_rays(_rb(gs), sd_c, None, 64, 128, lindisp=True, white_bkgd=False)
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], atol=5e-6)
+    ref = golden("g7_perturb")
+    rnd = cases.g7_rand_inputs(256)
+    r = O.render_rays(_rb(gs), sd_c, sd_f, 64, 128, white_bkgd=True, t_rand=T(rnd["t_rand"]), u=T(rnd["u"]))
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], atol=5e-6)
+
+
+def test_g7_ndc_render(golden):
+    sd_c, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
+    g, ref = cases.g7_ndc_inputs(), golden("g7_ndc")
+    rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 0., 1., ndc=True, H=g["H"], W=g["W"], focal=g["focal"])
+    r = O.render_rays(rb, sd_c, sd_f, 64, 128, white_bkgd=False)
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], atol=5e-6)
+
+
+def test_g8_dnerf_render_rays(golden):
+    sd = O.to_torch_sd(cases.weights_dnerf())
+    g = cases.g8_inputs()
+    for tv in (0.0, 0.5):
+        ref = golden(f"g8_dnerf_t{int(tv*10)}")
+        r = O.render_rays_dnerf(_rb(g, tv), sd, 64, 128, white_bkgd=True, retraw=True)
+        _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "z_vals", "z_std", "raw", "position_delta"], atol=5e-6)
+        assert set(ref.keys()) - {"crc"} == {"rgb_map", "disp_map", "acc_map", "z_vals", "position_delta", "raw", "z_std"}
+    ref = golden("g8_dnerf_coarse_only")
+    r = O.render_rays_dnerf(_rb(g, 0.25)[:128], sd, 64, 0, white_bkgd=True)
+    _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "z_vals", "position_delta"], atol=5e-6)
