@@ -1,0 +1,152 @@
+/* swnerf.h - C ABI of libswnerf_hip.so: the MI355X (gfx950) NeRF volumetric renderer.
+ *
+ * Drop-in boundary for the render hot path of daihangpku/SW-NeRF.
+ * The reference has no FFI layer: its "operator API" is the Python symbols of ray.py,
+ * embedder.py, model.py and the render_rays/run_network functions of the runner scripts.
+ * Each entry point below names the reference symbol (file:line under /root/reference)
+ * whose arithmetic it replaces; sw-nerf_amd/swnerf/ binds them with ctypes and
+ * re-exports the reference's Python names/signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless marked HOST;
+ *     the caller (torch) allocates inputs AND outputs; nothing is retained after return
+ *   - sizes are int64_t, flags int; `stream` is a hipStream_t passed as void*
+ *     (torch.cuda.current_stream().cuda_stream); all work is enqueued asynchronously
+ *   - return 0 on success, a negative SWNERF_E_* for argument errors, or a positive
+ *     hipError_t; swnerf_last_error() returns a thread-local message
+ *   - an optional output/input may be NULL where the comment says so
+ */
+#ifndef SWNERF_H
+#define SWNERF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWNERF_VERSION 100
+
+#define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
+#define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
+
+/* packed-network kinds (swnerf_packed_floats / swnerf_pack_*) */
+#define SWNERF_NET_CANON   0     /* vallina_NeRF == NeRFOriginal: 8x256, skip@4, view branch */
+#define SWNERF_NET_DNERF   1     /* DirectTemporalNeRF: deformation net then canonical net   */
+
+int         swnerf_version(void);
+const char* swnerf_last_error(void);
+
+/* ---- weights -------------------------------------------------------------------------
+ * The fused kernels stream weights in MFMA-fragment order (DESIGN.md "packed layout").
+ * Repack after every optimizer step.  `params` is a HOST array of DEVICE pointers in
+ * state_dict order of model.py:22-37 / 251-269:
+ *   [0..15]  pts_linears.{0..7}.{weight,bias}   (weight [out,in] row-major as in torch)
+ *   [16,17]  views_linears.0.{weight,bias}      [128, 256+C_dir]
+ *   [18,19]  feature_linear.{weight,bias}       [256,256]
+ *   [20,21]  alpha_linear.{weight,bias}         [1,256]
+ *   [22,23]  rgb_linear.{weight,bias}           [3,128]
+ * and for SWNERF_NET_DNERF additionally (model.py:108-126)
+ *   [24..39] _time.{0..7}.{weight,bias}         layer 0 is [256, C_pos + C_time]
+ *   [40,41]  _time_out.{weight,bias}            [3,256]
+ * L_pos / L_dir / L_time = number of frequency bands of the embedders
+ * (embedder.py:44-59: multires=10 -> C_pos 63, multires_views=4 -> C_dir 27,
+ * time multires=10 -> C_time 21).  Limits: L_pos <= 10, L_dir <= 4, L_time <= 10. */
+size_t swnerf_packed_floats(int kind);
+int swnerf_pack_net(int kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
+                    int L_time, float* packed, void* stream);
+
+/* ---- ray.py -------------------------------------------------------------------------- */
+
+/* get_rays (ray.py:10-38) for the pixel range [ray0, ray0+n) of an HxW image in row-major
+ * order.  focal_branch!=0 selects the float-focal branch (:26-29: cx=W/2, cy=H/2, fy=fx).
+ * c2w: HOST, 12 floats, row-major [3,4].  rays_o may be NULL. */
+int swnerf_get_rays(int H, int W, double fx, double fy, double cx, double cy, int focal_branch,
+                    const float* c2w /*HOST*/, int64_t ray0, int64_t n,
+                    float* rays_o /*[n,3]*/, float* rays_d /*[n,3]*/, void* stream);
+
+/* ndc_rays (ray.py:75-92).  In-place allowed (o_out==rays_o, d_out==rays_d). */
+int swnerf_ndc_rays(int H, int W, double focal, double near, const float* rays_o, const float* rays_d,
+                    int64_t n, float* o_out, float* d_out, void* stream);
+
+/* The ray-batch packing inside render() (nerf/run.py:137-158, d_nerf/run_dnerf.py:137-160):
+ * viewdirs = d/|d| taken BEFORE the optional NDC warp; rows = [o(3) d(3) near far (t) viewdirs(3)].
+ * has_time!=0 -> 12 columns with frame_time at column 8, else 11 columns. */
+int swnerf_pack_ray_batch(const float* rays_o, const float* rays_d, int64_t n, double near, double far,
+                          int has_time, double frame_time, int ndc, int H, int W, double ndc_focal,
+                          float* ray_batch, void* stream);
+
+/* raw2outputs (ray.py:155-198).  noise: NULL or [N,S] already multiplied by raw_noise_std.
+ * Any output may be NULL.  disp is NaN where acc==0, like the reference. */
+int swnerf_raw2outputs(const float* raw /*[N,S,4]*/, const float* z_vals /*[N,S]*/,
+                       const float* rays_d /*[N,3]*/, const float* noise, int64_t N, int S,
+                       int white_bkgd, float* rgb_map /*[N,3]*/, float* disp_map, float* acc_map,
+                       float* weights /*[N,S]*/, float* depth_map, void* stream);
+
+/* sample_pdf (ray.py:96-153).  bins [N,nb], weights [N,nb-1]; u: NULL -> det linspace(0,1,n_samples)
+ * (det=True), else [N,n_samples] uniforms (replaces torch.rand).  samples [N,n_samples].
+ * If z_vals ([N,S]) and z_sorted ([N,S+n_samples]) are given, also writes
+ * sort(cat[z_vals, samples]) (nerf/run.py:400); z_std ([N], std of samples, :416) may be NULL. */
+int swnerf_sample_pdf(const float* bins, const float* weights, int64_t N, int nb, int n_samples,
+                      const float* u, float* samples, const float* z_vals, int S, float* z_sorted,
+                      float* z_std, void* stream);
+
+/* ---- embedder.py --------------------------------------------------------------------- */
+
+/* Embedder.embed (embedder.py:33-42): x [M,d] -> [M, d*(1+2L)], frequency-major, sin before cos. */
+int swnerf_embed(const float* x, int64_t M, int d, int L, float* out, void* stream);
+
+/* ---- model.py ------------------------------------------------------------------------ */
+
+/* vallina_NeRF.forward / NeRFOriginal.forward (model.py:39-62, 273-296), use_viewdirs=True:
+ * x [M, C_pos+C_dir] already-embedded rows -> out [M,4] = [rgb(3), sigma].
+ * DirectTemporalNeRF.forward (model.py:138-151): packed kind DNERF, t_emb [M,C_time] = embedded
+ * frame time (ts[0]); run_deform==0 takes the `t==0 and zero_canonical` branch (dx=0);
+ * dx_out [M,3] may be NULL. */
+int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
+                       const float* t_emb, int L_time, int run_deform,
+                       float* out /*[M,4]*/, float* dx_out /*[M,3]*/, void* stream);
+
+/* ---- fused render pass (render_rays, nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480) -------
+ * One wavefront owns one ray: sampling -> positional encoding -> MLP (MFMA, register
+ * resident) -> alpha compositing -> optional hierarchical resampling, with no HBM traffic
+ * for pts / embeddings / activations / raw. */
+typedef struct swnerf_pass_args {
+    /* inputs */
+    const float* ray_batch;   /* [N, cols]  cols = 11, or 12 with frame_time at column 8 */
+    int64_t      n_rays;
+    int          cols;
+    int          kind;        /* SWNERF_NET_CANON / SWNERF_NET_DNERF */
+    const float* packed;      /* packed net of that kind */
+    int          run_deform;  /* DNERF only: 0 = `t==0 and zero_canonical` branch */
+    int          L_pos, L_dir, L_time;
+    int          n_samples;   /* S of THIS pass */
+    const float* z_vals;      /* NULL: coarse sampling from near/far (nerf/run.py:361-367);
+                                 else [N,S] given depths (fine pass, or run_dnerf.py:408) */
+    int          lindisp;
+    const float* t_rand;      /* NULL or [N,S] stratified jitter (perturb>0, nerf/run.py:369-383) */
+    const float* noise;       /* NULL or [N,S] density noise, pre-scaled (ray.py:176-184) */
+    int          white_bkgd;
+    /* per-ray outputs, any may be NULL */
+    float* rgb_map;           /* [N,3] */
+    float* disp_map;          /* [N]   */
+    float* acc_map;           /* [N]   */
+    float* depth_map;         /* [N]   */
+    /* per-sample outputs, any may be NULL */
+    float* weights;           /* [N,S]   */
+    float* raw;               /* [N,S,4] */
+    float* dx;                /* [N,S,3] position_delta (DNERF) */
+    float* z_out;             /* [N,S]   the depths this pass sampled */
+    /* hierarchical resampling after compositing (nerf/run.py:394-400), n_importance==0: off */
+    int          n_importance;
+    const float* u;           /* NULL: det (perturb==0); else [N,n_importance] uniforms */
+    float* z_fine;            /* [N, S+n_importance] sorted union */
+    float* z_std;             /* [N] std of the new samples, may be NULL */
+} swnerf_pass_args;
+
+int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

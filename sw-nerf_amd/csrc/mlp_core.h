@@ -1,0 +1,173 @@
+// mlp_core.h - the 8x256 NeRF MLP evaluated by ONE wavefront on a tile of 32 (ray,sample)
+// rows with v_mfma_f32_32x32x2_f32, activations resident in registers.
+//
+// Orientation: the transposed problem  H_out^T[256 x 32] = W[256 x K] . H_in^T[K x 32].
+//   A operand = weights (lane (i,h): W[32n+i][k]),  B operand = activations
+//   (lane (j,h): feature k of row j),  C/D = 32 out-features x 32 rows.
+// The C/D register map of this MFMA is  col = lane&31 (the row j),  row = sw_frow(reg, lane>>5)
+// - the SAME lane holds row j before and after, so the accumulator registers of layer L are
+// used, as they stand, as the B operands of layer L+1: register r of k-tile kt carries feature
+// 32*kt + sw_frow(r,h), and the host-side pack kernel permutes W's columns to match
+// (pack_kernels.hip).  No LDS round trip, no cross-lane movement between layers.
+//
+// Weights stream from L2 in "steps" of 1 KiB (4 MFMAs' A operands, one global_load_dwordx4
+// per lane) through a ring of SW_RING steps kept in flight; the ring never drains between
+// layers because the packed blob is laid out in execution order and ends with a copy of its
+// own first SW_RING steps.
+//
+// Reference arithmetic: model.py:39-62 (vallina_NeRF.forward), :273-296 (NeRFOriginal),
+// :128-151 (DirectTemporalNeRF.query_time / forward).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "swnerf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WStream {
+    const f32x4* p;          // this lane's slot of the CURRENT step
+    f32x4 ring[SW_RING];     // steps [cur, cur + SW_RING)
+    const f32x4* bias;       // this lane-half's 16 biases of the CURRENT output tile
+};
+
+__device__ __forceinline__ void ws_start(WStream& ws, const float* w, const float* bias, int lane) {
+    ws.p = reinterpret_cast<const f32x4*>(w) + lane;
+    ws.bias = reinterpret_cast<const f32x4*>(bias) + (lane >> 5) * 4;
+#pragma unroll
+    for (int i = 0; i < SW_RING; ++i) ws.ring[i] = ws.p[i * 64];
+}
+
+// after the last segment of a stream the ring already holds the blob's tail copy of the
+// first SW_RING steps: rewind the pointers only.
+__device__ __forceinline__ void ws_rewind(WStream& ws, const float* w, const float* bias, int lane) {
+    ws.p = reinterpret_cast<const f32x4*>(w) + lane;
+    ws.bias = reinterpret_cast<const f32x4*>(bias) + (lane >> 5) * 4;
+}
+
+// out[n] (+)= sum_kt  Wtile(n,kt) . kin[kt]       NT output tiles, KT input tiles.
+// INIT: accumulators start from the bias (so no separate bias pass); else accumulate.
+template <int NT, int KT, bool INIT>
+__device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws) {
+    constexpr int NS = NT * KT * 4;
+    static_assert(NS % SW_RING == 0, "segment must keep the ring phase");
+    if (INIT) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = ws.bias[n * 8 + g];
+                out[n][4 * g + 0] = b[0]; out[n][4 * g + 1] = b[1];
+                out[n][4 * g + 2] = b[2]; out[n][4 * g + 3] = b[3];
+            }
+        }
+        ws.bias += NT * 8;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int n = s / (KT * 4), kt = (s / 4) % KT, q = s % 4;
+        const f32x4 a = ws.ring[s % SW_RING];
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], kin[kt][4 * q + 0], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], kin[kt][4 * q + 1], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], kin[kt][4 * q + 2], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], kin[kt][4 * q + 3], out[n], 0, 0, 0);
+        ws.ring[s % SW_RING] = ws.p[(s + SW_RING) * 64];
+    }
+    ws.p += NS * 64;
+}
+
+// ---- positional encodings into B-operand slots (slot maps: swnerf_common.h) --------------
+__device__ __forceinline__ void pe_pos(float x0, float x1, float x2, int h, f32x16 (&e)[2]) {
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        float v;
+        if (a < 30) {
+            const int k = a / 3, c = a % 3;
+            const float xc = (c == 0) ? x0 : ((c == 1) ? x1 : x2);
+            v = sw_sin_or_cos(xc * (float)(1 << k), h);   // x * 2^k is exact (embedder.py:29,36)
+        } else if (a == 30) {
+            v = h ? x2 : x0;
+        } else {
+            v = h ? 0.f : x1;
+        }
+        e[a >> 4][a & 15] = v;
+    }
+}
+
+__device__ __forceinline__ void pe_dir(float d0, float d1, float d2, int h, f32x16& e) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        float v = 0.f;
+        if (a < 12) {
+            const int k = a / 3, c = a % 3;
+            const float dc = (c == 0) ? d0 : ((c == 1) ? d1 : d2);
+            v = sw_sin_or_cos(dc * (float)(1 << k), h);
+        } else if (a == 12) {
+            v = h ? d2 : d0;
+        } else if (a == 13) {
+            v = h ? 0.f : d1;
+        }
+        e[a] = v;
+    }
+}
+
+__device__ __forceinline__ void pe_time(float t, int h, f32x16& e) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        float v = 0.f;
+        if (a < 10) v = sw_sin_or_cos(t * (float)(1 << a), h);
+        else if (a == 10) v = h ? 0.f : t;
+        e[a] = v;
+    }
+}
+
+// ---- one trunk pass: 8 layers of width 256 with the skip at layer 5 ----------------------
+// deform_pass: layer 0 also takes the time-embedding k-tile (model.py:129: cat[new_pts, t]).
+// Returns with `in` = relu(layer-7 output) and `head` = the 1-tile head applied to it
+// (alpha_linear for the canonical net, _time_out for the deformation net).
+template <bool DNERF>
+__device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool deform_pass, int h,
+                                           f32x16 (&in)[8], f32x16 (&out)[8], f32x16& head, WStream& ws) {
+#pragma nounroll
+    for (int l = 0; l < 8; ++l) {
+        if (l == 0) {
+            if (DNERF && deform_pass) {
+                f32x16 k3[3];
+                k3[0] = emb[0]; k3[1] = emb[1];
+                pe_time(t, h, k3[2]);
+                seg_mfma<8, 3, true>(out, k3, ws);
+            } else {
+                seg_mfma<8, 2, true>(out, emb, ws);
+            }
+        } else {
+            seg_mfma<8, 8, true>(out, in, ws);
+            if (l == 5) seg_mfma<8, 2, false>(out, emb, ws);   // skip: cat[input_pts, h] (model.py:45-46)
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in[n][r] = fmaxf(out[n][r], 0.f);
+    }
+    f32x16 hd[1];
+    seg_mfma<1, 8, true>(hd, in, ws);
+    head = hd[0];
+}
+
+// ---- canonical tail: feature_linear (no activation) -> views_linears[0]+relu -> rgb_linear ---
+// `in` = relu(layer 7).  On return rgb[0..2] of lane half 0 = raw rgb of row j (model.py:49-58).
+__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[8], float d0, float d1, float d2,
+                                           int h, f32x16& rgb, WStream& ws) {
+    seg_mfma<8, 8, true>(out, in, ws);                      // feature = feature_linear(h)
+    f32x16 k9[9];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) k9[n] = out[n];
+    pe_dir(d0, d1, d2, h, k9[8]);                           // cat[feature, input_views]
+    f32x16 hv[4];
+    seg_mfma<4, 9, true>(hv, k9, ws);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+    f32x16 o[1];
+    seg_mfma<1, 4, true>(o, hv, ws);
+    rgb = o[0];
+}

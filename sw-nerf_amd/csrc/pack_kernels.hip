@@ -1,0 +1,136 @@
+// pack_kernels.hip - state_dict tensors -> the MFMA-fragment weight stream of mlp_core.h.
+//
+// For every GEMM segment (NT output tiles x KT input tiles of 32) the stream holds, per step
+// (n, kt, q) and lane (i = lane&31, h = lane>>5), the float4
+//     W[32n + i][ col(kt, r = 4q + e, h) ],  e = 0..3
+// i.e. exactly the A operand of the e-th of four consecutive v_mfma_f32_32x32x2_f32.
+// col() follows the B-operand slot of the activations: for a trunk k-tile register r of lane
+// half h carries feature 32*kt + sw_frow(r,h) (it is the previous layer's accumulator);
+// for an embedding k-tile the slot maps of swnerf_common.h apply.  Rows >= out_dim and pad
+// slots get 0.  Biases are stored per output tile as [h][r] = b[32n + sw_frow(r,h)] so a lane
+// reads the 16 initial accumulator values of its half with four float4 loads.
+//
+// Reference shapes: model.py:22-37 (vallina_NeRF), :251-269 (NeRFOriginal), :108-126 (_time net).
+#include <hip/hip_runtime.h>
+#include "../../include/swnerf.h"
+#include "swnerf_common.h"
+#include "host_util.h"
+
+enum { KT_TRUNK = 0, KT_POS0 = 1, KT_POS1 = 2, KT_DIR = 3, KT_TIME = 4 };
+
+struct PackSeg {
+    const float* W; const float* b;     // b == NULL: accumulate segment, no bias tile
+    int out_dim, in_dim, NT, KT;
+    int ktype[10], kbase[10];
+    int Lp, Ld, Lt;
+    float* dstW; float* dstB;
+};
+
+__global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
+    const int nsteps = s.NT * s.KT * 4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nsteps * SW_STEP_FLOATS) {
+        const int step = e / SW_STEP_FLOATS, rem = e % SW_STEP_FLOATS;
+        const int lane = rem >> 2, i4 = rem & 3;
+        const int n = step / (s.KT * 4), kt = (step >> 2) % s.KT, q = step & 3;
+        const int r = 4 * q + i4, i = lane & 31, h = lane >> 5;
+        const int row = 32 * n + i;
+        int col = -1;
+        switch (s.ktype[kt]) {
+            case KT_TRUNK: col = sw_frow(r, h); break;
+            case KT_POS0: col = sw_pos_col(r, h, s.Lp); break;
+            case KT_POS1: col = sw_pos_col(16 + r, h, s.Lp); break;
+            case KT_DIR: col = sw_dir_col(r, h, s.Ld); break;
+            case KT_TIME: col = sw_time_col(r, h, s.Lt); break;
+        }
+        float v = 0.f;
+        if (row < s.out_dim && col >= 0) v = s.W[(size_t)row * s.in_dim + s.kbase[kt] + col];
+        s.dstW[e] = v;
+    }
+    if (s.b && e < s.NT * SW_BIAS_TILE_FLOATS) {
+        const int n = e / SW_BIAS_TILE_FLOATS, rem = e % SW_BIAS_TILE_FLOATS;
+        const int h = rem >> 4, r = rem & 15;
+        const int row = 32 * n + sw_frow(r, h);
+        s.dstB[e] = (row < s.out_dim) ? s.b[row] : 0.f;
+    }
+}
+
+struct Packer {
+    hipStream_t st; float* w; float* b; int Lp, Ld, Lt; int rc;
+    void seg(const float* W, const float* bias, int out_dim, int in_dim, int NT, int KT, const int* kt, const int* kb) {
+        if (rc) return;
+        PackSeg s;
+        s.W = W; s.b = bias; s.out_dim = out_dim; s.in_dim = in_dim; s.NT = NT; s.KT = KT;
+        for (int i = 0; i < 10; ++i) { s.ktype[i] = i < KT ? kt[i] : 0; s.kbase[i] = i < KT ? kb[i] : 0; }
+        s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
+        const int total = NT * KT * 4 * SW_STEP_FLOATS;
+        hipLaunchKernelGGL(pack_seg_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s);
+        rc = sw_check(hipGetLastError(), "pack_net launch");
+        w += total;
+        if (bias) b += NT * SW_BIAS_TILE_FLOATS;
+    }
+    // one 8-layer trunk + 1-tile head; P = {W0,b0,...,W7,b7}, head = {Wh,bh}
+    void trunk(const float* const* P, const float* Wh, const float* bh, int head_out, int Cpos, int Ctime) {
+        const int t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int b8[8];
+        for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
+        const int e3[3] = {KT_POS0, KT_POS1, KT_TIME};
+        const int eb[3] = {0, 0, Cpos};
+        seg(P[0], P[1], 256, Cpos + Ctime, 8, Ctime ? 3 : 2, e3, eb);           // layer 0
+        for (int l = 1; l < 8; ++l) {
+            if (l == 5) {                                                          // input = cat[pts_emb, h]
+                int b5[8];
+                for (int i = 0; i < 8; ++i) b5[i] = Cpos + 32 * i;
+                seg(P[10], P[11], 256, Cpos + 256, 8, 8, t8, b5);
+                seg(P[10], nullptr, 256, Cpos + 256, 8, 2, e3, eb);
+            } else {
+                seg(P[2 * l], P[2 * l + 1], 256, 256, 8, 8, t8, b8);
+            }
+        }
+        seg(Wh, bh, head_out, 256, 1, 8, t8, b8);
+    }
+};
+
+extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, int L_dir, int L_time, float* packed, void* stream) {
+    if (!params || !packed) return sw_fail(SWNERF_E_ARG, "pack_net: NULL pointer");
+    if (kind != SWNERF_NET_CANON && kind != SWNERF_NET_DNERF) return sw_fail(SWNERF_E_ARG, "pack_net: unknown kind %d", kind);
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4 || L_time < 0 || L_time > 10)
+        return sw_fail(SWNERF_E_UNSUPP, "pack_net: embedder bands (%d,%d,%d) exceed (10,4,10)", L_pos, L_dir, L_time);
+    const int np = kind == SWNERF_NET_CANON ? 24 : 42;
+    for (int i = 0; i < np; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net: params[%d] is NULL", i);
+    const int Cpos = 3 * (1 + 2 * L_pos), Cdir = 3 * (1 + 2 * L_dir), Ctime = 1 + 2 * L_time;
+    hipStream_t st = (hipStream_t)stream;
+    const int t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b8[8];
+    for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
+
+    auto canon = [&](Packer& pk) {
+        pk.trunk(params, params[20], params[21], 1, Cpos, 0);                      // ... ALPHA
+        pk.seg(params[18], params[19], 256, 256, 8, 8, t8, b8);                    // FEAT
+        int vt[9], vb[9];
+        for (int i = 0; i < 8; ++i) { vt[i] = KT_TRUNK; vb[i] = 32 * i; }
+        vt[8] = KT_DIR; vb[8] = 256;
+        pk.seg(params[16], params[17], 128, 256 + Cdir, 4, 9, vt, vb);             // VIEWS
+        pk.seg(params[22], params[23], 3, 128, 1, 4, t8, b8);                      // RGB
+    };
+    auto tail = [&](float* wbase, const float* head) {
+        return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
+    };
+
+    int rc = 0;
+    if (kind == SWNERF_NET_DNERF) {
+        Packer pk{st, packed, packed + SW_DNERF_W_FLOATS, L_pos, L_dir, L_time, 0};
+        pk.trunk(params + 24, params[40], params[41], 3, Cpos, Ctime);             // deformation net
+        canon(pk);
+        if (pk.rc) return pk.rc;
+        if (pk.w != packed + (size_t)(SW_DEFORM_STEPS + SW_CANON_STEPS) * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
+        if ((rc = tail(pk.w, packed))) return rc;
+        packed += SW_DNERF_A_FLOATS;                                               // then the canon-only blob
+    }
+    Packer pk{st, packed, packed + SW_CANON_W_FLOATS, L_pos, L_dir, L_time, 0};
+    canon(pk);
+    if (pk.rc) return pk.rc;
+    if (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_FLOATS)
+        return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
+    return tail(pk.w, packed);
+}

@@ -1,0 +1,379 @@
+// render_kernels.hip - fused NeRF render pass for gfx950 (MI355X): ONE wavefront owns ONE ray.
+//
+// For each 32-sample tile of its ray the wave computes depths -> points -> positional
+// encoding (VALU) -> [deformation MLP ->] canonical MLP (MFMA, registers: mlp_core.h) ->
+// alpha compositing (wave scan), and after the last tile optionally the hierarchical
+// resampling (inverse-CDF + bitonic merge in the wave's LDS slice).  Nothing per-sample
+// touches HBM unless the caller asks for it (raw / weights / dx / z_out).
+//
+// Reference: render_rays nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480; raw2outputs
+// ray.py:155-198; sample_pdf ray.py:96-153; run_network nerf/run.py:73-87.
+#include <hip/hip_runtime.h>
+#include "../../include/swnerf.h"
+#include "swnerf_common.h"
+#include "mlp_core.h"
+#include "host_util.h"
+
+#define SW_LDS_SC 256                    // max coarse samples when resampling
+#define SW_LDS_SORT 1024                 // max S + n_importance (padded to a power of two)
+#define SW_LDS_WAVE_FLOATS (3 * SW_LDS_SC + SW_LDS_SORT)
+
+struct PassDev {
+    swnerf_pass_args a;
+    const float* w0;        // weight stream this pass runs per tile
+    const float* b0;        // its bias stream
+    int two_pass;           // 1: deformation net then canonical net
+    int sort_n;             // power of two >= S + n_importance
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float wave32_sum(float v) {   // sum over the 32 lanes of each half
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+
+__device__ __forceinline__ float z_linear(const swnerf_pass_args& a, float near, float far, int s) {
+    const float t = sw_linspace(0.f, 1.f, a.n_samples, s);
+    if (!a.lindisp) return near * (1.f - t) + far * t;                       // nerf/run.py:363
+    return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);                   // nerf/run.py:365
+}
+
+// depth of sample s (0 <= s < S) of this ray
+__device__ __forceinline__ float z_sample(const swnerf_pass_args& a, int64_t ray, float near, float far, int s) {
+    const int S = a.n_samples;
+    if (a.z_vals) return a.z_vals[ray * S + s];
+    const float zs = z_linear(a, near, far, s);
+    if (!a.t_rand) return zs;
+    // stratified jitter, nerf/run.py:369-383
+    const float upper = (s < S - 1) ? .5f * (z_linear(a, near, far, s + 1) + zs) : zs;
+    const float lower = (s > 0) ? .5f * (zs + z_linear(a, near, far, s - 1)) : zs;
+    return lower + (upper - lower) * a.t_rand[ray * S + s];
+}
+
+// ------------------------------------------------------------------------------------------
+template <bool DNERF>
+__global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    const swnerf_pass_args& a = P.a;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= a.n_rays) return;                 // wave-uniform; the kernel has no block barrier
+    float* lds = lds_all + wv * SW_LDS_WAVE_FLOATS;
+    float* zc = lds;                             // [S]   depths of this pass
+    float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
+    float* cdf = lds + 2 * SW_LDS_SC;            // [S-1]
+    float* srt = lds + 3 * SW_LDS_SC;            // [sort_n]
+
+    const int S = a.n_samples;
+    const bool resample = a.n_importance > 0;
+    const float* rb = a.ray_batch + ray * a.cols;
+    const float ox = rb[0], oy = rb[1], oz = rb[2], dx = rb[3], dy = rb[4], dz = rb[5];
+    const float near = rb[6], far = rb[7];
+    const float ft = (a.cols == 12) ? rb[8] : 0.f;
+    const float v0 = rb[a.cols - 3], v1 = rb[a.cols - 2], v2 = rb[a.cols - 1];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
+
+    WStream ws;
+    ws_start(ws, P.w0, P.b0, lane);
+
+    float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
+    double Tc = 1.0;                              // transmittance carried across tiles
+    const int ntiles = (S + 31) >> 5;
+#pragma nounroll
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int s = tile * 32 + j;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        const float z = z_sample(a, ray, near, far, sc);
+        const float zn = (s + 1 < S) ? z_sample(a, ray, near, far, s + 1) : z;
+        // pts = rays_o + rays_d * z  (two roundings, nerf/run.py:385)
+        float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+
+        f32x16 emb[2], in[8], out[8], head, rgb;
+        pe_pos(px, py, pz, h, emb);
+        if (DNERF) {
+#pragma nounroll
+            for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
+                trunk_pass<true>(emb, ft, pass == 0, h, in, out, head, ws);
+                if (pass == 0) {
+                    // dx = _time_out(h): rows sit on lane half 0, registers 0..2 (model.py:136,146-149)
+                    const float ex = __shfl(head[0], j), ey = __shfl(head[1], j), ez = __shfl(head[2], j);
+                    if (a.dx && live && h == 0) {
+                        float* o = a.dx + (ray * S + s) * 3;
+                        o[0] = ex; o[1] = ey; o[2] = ez;
+                    }
+                    px = px + ex; py = py + ey; pz = pz + ez;
+                    pe_pos(px, py, pz, h, emb);                              // re-embed (model.py:148-149)
+                }
+            }
+            if (!P.two_pass && a.dx && live && h == 0) {
+                float* o = a.dx + (ray * S + s) * 3;
+                o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;                          // model.py:144-145
+            }
+        } else {
+            trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+        }
+        canon_tail(in, out, v0, v1, v2, h, rgb, ws);
+        ws_rewind(ws, P.w0, P.b0, lane);
+
+        // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
+        const float c0 = __shfl(rgb[0], j), c1 = __shfl(rgb[1], j), c2 = __shfl(rgb[2], j);
+        float sg = __shfl(head[0], j);
+        if (a.raw && live && h == 0) {
+            f32x4 r4 = {c0, c1, c2, sg};
+            *reinterpret_cast<f32x4*>(a.raw + (ray * S + s) * 4) = r4;
+        }
+        if (a.noise) sg += a.noise[ray * S + sc];
+        float dist = (s + 1 < S) ? (zn - z) : 1e10f;
+        dist = dist * dnorm;
+        float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
+        if (!live) alpha = 0.f;
+        double ps = (double)(1.f - alpha + 1e-10f);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const double up = __shfl_up(ps, o, 32);
+            if (j >= o) ps *= up;
+        }
+        double ex = __shfl_up(ps, 1, 32);
+        if (j == 0) ex = 1.0;
+        const float T = (float)(Tc * ex);                                    // exclusive cumprod (ray.py:188)
+        Tc *= __shfl(ps, 31, 32);
+        const float w = alpha * T;
+        if (live) {
+            if (a.weights && h == 0) a.weights[ray * S + s] = w;
+            if (a.z_out && h == 0) a.z_out[ray * S + s] = z;
+            if (resample && h == 0) { zc[s] = z; wc[s] = w; }
+        }
+        pr += w * (1.f / (1.f + expf(-c0)));
+        pg += w * (1.f / (1.f + expf(-c1)));
+        pb += w * (1.f / (1.f + expf(-c2)));
+        pd += w * z;
+        pa += w;
+    }
+
+    pr = wave32_sum(pr); pg = wave32_sum(pg); pb = wave32_sum(pb);
+    pd = wave32_sum(pd); pa = wave32_sum(pa);
+    if (lane == 0) {
+        if (a.rgb_map) {
+            const float bg = a.white_bkgd ? (1.f - pa) : 0.f;                // ray.py:195-196
+            a.rgb_map[ray * 3 + 0] = pr + bg;
+            a.rgb_map[ray * 3 + 1] = pg + bg;
+            a.rgb_map[ray * 3 + 2] = pb + bg;
+        }
+        if (a.depth_map) a.depth_map[ray] = pd;
+        if (a.acc_map) a.acc_map[ray] = pa;
+        if (a.disp_map) {
+            const float q = pd / pa;                                         // NaN when acc == 0, kept (ray.py:192)
+            a.disp_map[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+        }
+    }
+    if (!resample) return;
+
+    // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; then sort (nerf/run.py:396-400)
+    wave_lds_sync();
+    const int nb = S - 1, nw = S - 2, Ni = a.n_importance;
+    float part = 0.f;
+    for (int i = lane; i < nw; i += 64) part += wc[i + 1] + 1e-5f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    const float wsum = part;
+    double carry = 0.0;
+    for (int base = 0; base < nw; base += 64) {      // cumsum accumulates in double like ATen's CPU kernel
+        const int i = base + lane;
+        double v = (i < nw) ? (double)((wc[i + 1] + 1e-5f) / wsum) : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(v, o, 64);
+            if (lane >= o) v += up;
+        }
+        if (i < nw) cdf[i + 1] = (float)(carry + v);
+        carry += __shfl(v, 63, 64);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    wave_lds_sync();
+    double sm = 0.0;
+    for (int m = lane; m < Ni; m += 64) {
+        const float u = a.u ? a.u[ray * Ni + m] : sw_linspace(0.f, 1.f, Ni, m);
+        int lo = 0, hi = nb;                         // searchsorted(cdf, u, right=True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(0, lo - 1), above = min(nb - 1, lo);
+        const float cb = cdf[below], ca = cdf[above];
+        const float bb = .5f * (zc[below + 1] + zc[below]), ba = .5f * (zc[above + 1] + zc[above]);
+        float den = ca - cb;
+        if (den < 1e-5f) den = 1.f;
+        const float smp = bb + (u - cb) / den * (ba - bb);
+        srt[S + m] = smp;
+        sm += (double)smp;
+    }
+    for (int i = lane; i < S; i += 64) srt[i] = zc[i];
+    for (int i = S + Ni + lane; i < P.sort_n; i += 64) srt[i] = __builtin_inff();
+    wave_lds_sync();
+    if (a.z_std) {                                   // torch.std(z_samples, unbiased=False), nerf/run.py:416
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const double mean = sm / Ni;
+        double var = 0.0;
+        for (int m = lane; m < Ni; m += 64) { const double d = (double)srt[S + m] - mean; var += d * d; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+        if (lane == 0) a.z_std[ray] = (float)sqrt(var / Ni);
+    }
+    for (int k = 2; k <= P.sort_n; k <<= 1) {        // bitonic sort of the wave's slice
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int idx = lane; idx < (P.sort_n >> 1); idx += 64) {
+                const int i = 2 * idx - (idx & (jj - 1));
+                const int l = i + jj;
+                const float x = srt[i], y = srt[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { srt[i] = y; srt[l] = x; }
+            }
+            wave_lds_sync();
+        }
+    }
+    for (int i = lane; i < S + Ni; i += 64) a.z_fine[ray * (S + Ni) + i] = srt[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// model.forward(x) on already-embedded rows (API parity with run_network / extract_mesh):
+// one wave per 32 rows; the embedded features are gathered from x into the B-operand slots.
+struct MlpDev {
+    const float* x; int64_t M; int C;   // C = C_pos + C_dir
+    int Lp, Ld, Lt, Cpos;
+    const float* t_emb; int Ct;
+    const float* w0; const float* b0; int two_pass;
+    float* out; float* dx;
+};
+
+template <bool DNERF>
+__global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    if (tile * 32 >= P.M) return;
+    const int64_t row = tile * 32 + j;
+    const bool live = row < P.M;
+    const float* xr = P.x + (live ? row : P.M - 1) * P.C;
+
+    f32x16 emb[2], in[8], out[8], head, rgb;
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        const int col = sw_pos_col(a, h, P.Lp);
+        emb[a >> 4][a & 15] = (col >= 0) ? xr[col] : 0.f;
+    }
+    WStream ws;
+    ws_start(ws, P.w0, P.b0, lane);
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    if (DNERF) {
+        const float ft = P.t_emb ? P.t_emb[(live ? row : P.M - 1) * P.Ct] : 0.f;   // column 0 of gamma(t) is t
+#pragma nounroll
+        for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
+            trunk_pass<true>(emb, ft, pass == 0, h, in, out, head, ws);
+            if (pass == 0) {
+                ex = __shfl(head[0], j); ey = __shfl(head[1], j); ez = __shfl(head[2], j);
+                pe_pos(xr[0] + ex, xr[1] + ey, xr[2] + ez, h, emb);      // embed_fn(input_pts_orig + dx)
+            }
+        }
+    } else {
+        trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+    }
+    // view-direction features: gathered like the position ones
+    f32x16 k9[9];
+    seg_mfma<8, 8, true>(out, in, ws);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) k9[n] = out[n];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int col = sw_dir_col(a, h, P.Ld);
+        k9[8][a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
+    }
+    f32x16 hv[4];
+    seg_mfma<4, 9, true>(hv, k9, ws);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+    f32x16 o1[1];
+    seg_mfma<1, 4, true>(o1, hv, ws);
+    rgb = o1[0];
+    if (live && h == 0) {
+        f32x4 r4 = {rgb[0], rgb[1], rgb[2], head[0]};
+        *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
+        if (P.dx) { P.dx[row * 3 + 0] = ex; P.dx[row * 3 + 1] = ey; P.dx[row * 3 + 2] = ez; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static int stream_ptrs(int kind, const float* packed, int run_deform, const float** w0, const float** b0, int* two) {
+    if (kind == SWNERF_NET_CANON) {
+        *w0 = packed; *b0 = packed + SW_CANON_W_FLOATS; *two = 0;
+    } else if (kind == SWNERF_NET_DNERF) {
+        if (run_deform) { *w0 = packed; *b0 = packed + SW_DNERF_W_FLOATS; *two = 1; }
+        else { const float* c = packed + SW_DNERF_A_FLOATS; *w0 = c; *b0 = c + SW_CANON_W_FLOATS; *two = 0; }
+    } else {
+        return sw_fail(SWNERF_E_ARG, "unknown net kind %d", kind);
+    }
+    return 0;
+}
+
+extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
+    if (!args) return sw_fail(SWNERF_E_ARG, "render_pass: NULL args");
+    const swnerf_pass_args& a = *args;
+    if (!a.ray_batch || !a.packed) return sw_fail(SWNERF_E_ARG, "render_pass: NULL ray_batch/packed");
+    if (a.n_rays < 0 || a.n_samples < 2) return sw_fail(SWNERF_E_ARG, "render_pass: n_rays %lld, n_samples %d", (long long)a.n_rays, a.n_samples);
+    if (a.cols != 11 && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: ray_batch must have 11 or 12 columns (use_viewdirs), got %d", a.cols);
+    if (a.kind == SWNERF_NET_DNERF && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: D-NeRF needs the frame_time column");
+    if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4 || a.L_time < 0 || a.L_time > 10)
+        return sw_fail(SWNERF_E_UNSUPP, "render_pass: embedder bands (%d,%d,%d) exceed (10,4,10)", a.L_pos, a.L_dir, a.L_time);
+    if (a.z_vals && a.t_rand) return sw_fail(SWNERF_E_ARG, "render_pass: t_rand only applies to coarse sampling");
+    PassDev P;
+    P.a = a;
+    int rc = stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.two_pass);
+    if (rc) return rc;
+    P.sort_n = 0;
+    size_t lds = 0;
+    if (a.n_importance > 0) {
+        if (!a.z_fine) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
+        if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
+            return sw_fail(SWNERF_E_UNSUPP, "render_pass: resampling supports 3<=N_samples<=%d and N_samples+N_importance<=%d", SW_LDS_SC, SW_LDS_SORT);
+        int p2 = 2;
+        while (p2 < a.n_samples + a.n_importance) p2 <<= 1;
+        P.sort_n = p2;
+        lds = 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
+    }
+    if (a.n_rays == 0) return 0;
+    const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
+    else hipLaunchKernelGGL(render_pass_kernel<false>, grid, block, lds, st, P);
+    return sw_check(hipGetLastError(), "render_pass launch");
+}
+
+extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
+                                  const float* t_emb, int L_time, int run_deform, float* out, float* dx_out, void* stream) {
+    if (!packed || !x || !out || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_forward: NULL pointer or negative M");
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4 || L_time < 0 || L_time > 10)
+        return sw_fail(SWNERF_E_UNSUPP, "mlp_forward: embedder bands (%d,%d,%d) exceed (10,4,10)", L_pos, L_dir, L_time);
+    if (kind == SWNERF_NET_DNERF && run_deform && !t_emb) return sw_fail(SWNERF_E_ARG, "mlp_forward: D-NeRF deformation needs t_emb");
+    MlpDev P;
+    P.x = x; P.M = M; P.Lp = L_pos; P.Ld = L_dir; P.Lt = L_time;
+    P.Cpos = 3 * (1 + 2 * L_pos); P.C = P.Cpos + 3 * (1 + 2 * L_dir);
+    P.t_emb = t_emb; P.Ct = 1 + 2 * L_time;
+    P.out = out; P.dx = dx_out;
+    int rc = stream_ptrs(kind, packed, run_deform, &P.w0, &P.b0, &P.two_pass);
+    if (rc) return rc;
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    if (kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(mlp_forward_kernel<true>, grid, block, 0, st, P);
+    else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, 0, st, P);
+    return sw_check(hipGetLastError(), "mlp_forward launch");
+}

@@ -1,0 +1,96 @@
+// swnerf_common.h - layout constants and small math helpers shared by the pack kernel,
+// the fused MLP/render kernels and the host-side unit checks (compiles as plain C++ too).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SW_HD __host__ __device__ __forceinline__
+#else
+#define SW_HD static inline
+#endif
+
+// ---- packed weight stream -------------------------------------------------------------
+// One "step" = the A operands of 4 consecutive v_mfma_f32_32x32x2_f32: 64 lanes x float4
+// = 256 floats = 1 KiB, read by ONE global_load_dwordx4 per lane.
+#define SW_STEP_FLOATS 256
+#define SW_RING 8                 // steps kept in flight per wave (prefetch ring)
+#define SW_BIAS_TILE_FLOATS 32    // per 32-feature output tile: [h(2)][r(16)]
+
+// steps per segment (NT * KT * 4)
+#define SW_STEPS_EMB    64        // 8 n-tiles x 2 pos-emb k-tiles
+#define SW_STEPS_EMB_T  96        // 8 x 3 (pos emb + time emb): deformation layer 0
+#define SW_STEPS_TRUNK  256       // 8 x 8
+#define SW_STEPS_HEAD   32        // 1 x 8   (alpha_linear / _time_out)
+#define SW_STEPS_VIEWS  144       // 4 x 9   (feature 8 tiles + dir emb 1 tile)
+#define SW_STEPS_RGB    16        // 1 x 4
+// canonical net stream: L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | ALPHA | FEAT | VIEWS | RGB
+#define SW_CANON_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
+                        2 * SW_STEPS_TRUNK + SW_STEPS_HEAD + SW_STEPS_TRUNK + SW_STEPS_VIEWS + SW_STEPS_RGB)
+#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 1 + 8 + 4 + 1)
+// deformation net stream: D0 | D1..D4 | D5(trunk) D5(emb) | D6 D7 | DOUT
+#define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
+                         2 * SW_STEPS_TRUNK + SW_STEPS_HEAD)
+#define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 1)
+
+// blob CANON : [canon steps][ring tail = copy of first SW_RING steps][canon bias]
+#define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_CANON_FLOATS     (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
+// (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
+#define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_DNERF_A_FLOATS   (SW_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
+#define SW_DNERF_FLOATS     (SW_DNERF_A_FLOATS + SW_CANON_FLOATS)
+
+// C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile
+SW_HD int sw_frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- embedding slot maps ---------------------------------------------------------------
+// Which column of the reference embedding (embedder.py:33-42: [x, sin(2^0 x), cos(2^0 x), ...],
+// blocks d wide) sits in B-operand slot (a, h) of an embedding k-tile; -1 = zero pad.
+// Lane half h=0 evaluates the sines, h=1 the cosines of the same 16 arguments per tile.
+SW_HD int sw_pos_col(int a /*0..31 over two tiles*/, int h, int L) {
+    if (a < 30) { int k = a / 3, c = a % 3; return k < L ? 3 + 6 * k + 3 * h + c : -1; }
+    if (a == 30) return h == 0 ? 0 : 2;
+    return h == 0 ? 1 : -1;
+}
+SW_HD int sw_dir_col(int a /*0..15*/, int h, int L) {
+    if (a < 12) { int k = a / 3, c = a % 3; return k < L ? 3 + 6 * k + 3 * h + c : -1; }
+    if (a == 12) return h == 0 ? 0 : 2;
+    if (a == 13) return h == 0 ? 1 : -1;
+    return -1;
+}
+SW_HD int sw_time_col(int a /*0..15*/, int h, int L) {
+    if (a < 10) return a < L ? 1 + 2 * a + h : -1;
+    if (a == 10) return h == 0 ? 0 : -1;
+    return -1;
+}
+
+// ---- sin / cos -------------------------------------------------------------------------
+// sin(y) for want_cos==0, cos(y) for want_cos==1, |y| up to ~1e5 (the top positional band is
+// 512*x).  Three-term Cody-Waite reduction by pi/2 with FMAs, then the Cephes float minimax
+// polynomials on [-pi/4, pi/4]; cos(y) = sin(y + pi/2) is a quadrant shift, so both lane
+// halves run the same instruction stream.  Max abs error vs double libm ~1.2e-7 (test_host_math).
+SW_HD float sw_sin_or_cos(float y, int want_cos) {
+    const float n = rintf(y * 0.63661977236758134f);
+    float r = fmaf(-n, 1.57079637050628662e+00f, y);
+    r = fmaf(-n, -4.37113882867379223e-08f, r);
+    r = fmaf(-n, -1.71512451306010346e-15f, r);
+    const int q = (int)n + want_cos;
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);                                  // sin(r)
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));               // cos(r)
+    float v = (q & 1) ? pc : ps;
+    return (q & 2) ? -v : v;
+}
+
+// torch.linspace(start, end, steps)[i] in float32 as the ATen CPU kernel computes it:
+// step = (end-start)/(steps-1); i < steps/2 ? fma(step, i, start) : fma(-step, steps-1-i, end)
+SW_HD float sw_linspace(float start, float end, int steps, int i) {
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
+}

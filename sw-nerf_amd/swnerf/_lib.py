@@ -1,0 +1,100 @@
+"""ctypes binding of libswnerf_hip.so (include/swnerf.h).  There is NO fallback: if the
+shared library is missing or a GPU is absent, every op raises - the product path never
+routes through a CPU implementation."""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_double, c_void_p, c_size_t, c_char_p, POINTER, Structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswnerf_hip.so")
+
+NET_CANON, NET_DNERF = 0, 1
+
+EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
+           "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs",
+           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_render_pass"]
+
+
+class PassArgs(Structure):
+    """struct swnerf_pass_args (include/swnerf.h)"""
+    _fields_ = [
+        ("ray_batch", c_void_p), ("n_rays", c_int64), ("cols", c_int), ("kind", c_int),
+        ("packed", c_void_p), ("run_deform", c_int), ("L_pos", c_int), ("L_dir", c_int), ("L_time", c_int),
+        ("n_samples", c_int), ("z_vals", c_void_p), ("lindisp", c_int), ("t_rand", c_void_p),
+        ("noise", c_void_p), ("white_bkgd", c_int),
+        ("rgb_map", c_void_p), ("disp_map", c_void_p), ("acc_map", c_void_p), ("depth_map", c_void_p),
+        ("weights", c_void_p), ("raw", c_void_p), ("dx", c_void_p), ("z_out", c_void_p),
+        ("n_importance", c_int), ("u", c_void_p), ("z_fine", c_void_p), ("z_std", c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"swnerf: {LIB_PATH} not found - build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the render path")
+    L = ctypes.CDLL(LIB_PATH)
+    L.swnerf_version.restype = c_int
+    L.swnerf_last_error.restype = c_char_p
+    L.swnerf_packed_floats.restype = c_size_t
+    L.swnerf_packed_floats.argtypes = [c_int]
+    L.swnerf_pack_net.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_get_rays.argtypes = [c_int, c_int, c_double, c_double, c_double, c_double, c_int,
+                                  POINTER(ctypes.c_float), c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+    L.swnerf_ndc_rays.argtypes = [c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int64,
+                                  c_void_p, c_void_p, c_void_p]
+    L.swnerf_pack_ray_batch.argtypes = [c_void_p, c_void_p, c_int64, c_double, c_double, c_int, c_double,
+                                        c_int, c_int, c_int, c_double, c_void_p, c_void_p]
+    L.swnerf_raw2outputs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_sample_pdf.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_embed.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_mlp_forward.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_render_pass.argtypes = [POINTER(PassArgs), c_void_p]
+    for name in EXPORTS:
+        if name not in ("swnerf_last_error", "swnerf_packed_floats"):
+            getattr(L, name).restype = c_int
+    if L.swnerf_version() != 100:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 100")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().swnerf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"swnerf.{what} failed (code {rc}): {msg}")
+
+
+def stream_of(t):
+    import torch
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def dev_f32(t, name, shape_last=None):
+    """Validate a device operand the way the C ABI requires (fp32, contiguous, cuda)."""
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"swnerf: {name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"swnerf: {name} must live on the GPU (got device {t.device}); "
+                           "the HIP render path has no CPU implementation")
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if shape_last is not None and t.shape[-1] != shape_last:
+        raise ValueError(f"swnerf: {name} last dim must be {shape_last}, got {tuple(t.shape)}")
+    return t

@@ -1,0 +1,220 @@
+"""Drop-in for the reference's model.py: vallina_NeRF, NeRFOriginal, DirectTemporalNeRF and the
+NeRF.get_by_name factory as nn.Modules with the SAME parameter names and shapes (so the
+reference's checkpoints `network_fn_state_dict` / `network_fine_state_dict` load unchanged,
+nerf/run.py:269-280), whose forward runs the register-resident MFMA kernel
+(csrc/mlp_core.h) through `swnerf_mlp_forward`.
+
+Built configuration = the one every shipped config uses: D=8, W=256, skips=[4],
+use_viewdirs=True.  Anything else constructs (state_dict parity) but raises at forward.
+TNeRF (model.py:152-210) is out of scope.
+Backward is not built yet: forward outputs carry a grad_fn
+that raises if autograd reaches it."""
+import ctypes
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
+import numpy as np
+
+from . import _lib
+from .embedder import img2mse, mse2psnr, to8b  # noqa: F401
+
+_CANON_ORDER = ([f"pts_linears.{i}.{p}" for i in range(8) for p in ("weight", "bias")]
+                + [f"{n}.{p}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear")
+                   for p in ("weight", "bias")])
+_DEFORM_ORDER = ([f"_time.{i}.{p}" for i in range(8) for p in ("weight", "bias")]
+                 + [f"_time_out.{p}" for p in ("weight", "bias")])
+
+
+def _bands(ch, d):
+    """number of frequency bands L with ch == d*(1+2L), or None"""
+    if ch % d:
+        return None
+    q = ch // d - 1
+    return q // 2 if q >= 0 and q % 2 == 0 else None
+
+
+class _NoBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, *params):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, *g):
+        raise NotImplementedError(
+            "swnerf: the backward pass of the fused NeRF MLP is not built yet (SURVEY.md 8f rank 1); "
+            "run the render path under torch.no_grad()")
+
+
+def _tag_no_backward(out, module):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        return _NoBackward.apply(out, *list(module.parameters()))
+    return out
+
+
+class _PackedMixin:
+    """Caches the MFMA-ordered weight stream; repacks when any parameter changed in place
+    (optimizer step, load_state_dict) or moved."""
+
+    def _init_pack(self):
+        self._pack_key = None
+        self._packed = None
+
+    def _check_arch(self):
+        if not (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.use_viewdirs):
+            raise NotImplementedError(
+                f"swnerf: only D=8, W=256, skips=[4], use_viewdirs=True is built as a HIP kernel "
+                f"(got D={self.D}, W={self.W}, skips={self.skips}, use_viewdirs={self.use_viewdirs})")
+        Lp, Ld = _bands(self.input_ch, 3), _bands(self.input_ch_views, 3)
+        if Lp is None or Ld is None or Lp > 10 or Ld > 4:
+            raise NotImplementedError(
+                f"swnerf: input_ch={self.input_ch}/input_ch_views={self.input_ch_views} must be 3*(1+2L) with "
+                "L<=10 / L<=4 (the reference's get_embedder output sizes)")
+        return Lp, Ld
+
+    def _pack_params(self):
+        raise NotImplementedError
+
+    def packed(self):
+        """(kind, packed float tensor, L_pos, L_dir, L_time)"""
+        kind, names, Lp, Ld, Lt = self._pack_params()
+        sd = dict(self.named_parameters())
+        ps = [sd[n] for n in names]
+        dev = ps[0].device
+        if not ps[0].is_cuda:
+            raise RuntimeError("swnerf: module parameters must be on the GPU (call .to('cuda')); no CPU fallback")
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._pack_key:
+            L = _lib.lib()
+            ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
+            arr = (ctypes.c_void_p * len(ps32))(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_floats(kind), dtype=torch.float32, device=dev)
+            _lib.check(L.swnerf_pack_net(kind, arr, Lp, Ld, Lt, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net")
+            self._packed, self._pack_key = buf, key
+        return kind, self._packed, Lp, Ld, Lt
+
+    def _forward_hip(self, x, t_emb=None, run_deform=0, want_dx=False):
+        kind, packed, Lp, Ld, Lt = self.packed()
+        x = _lib.dev_f32(x, "x", self.input_ch + self.input_ch_views)
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, x.shape[-1])
+        M = flat.shape[0]
+        out = torch.empty((M, 4), dtype=torch.float32, device=x.device)
+        dx = torch.empty((M, 3), dtype=torch.float32, device=x.device) if want_dx else None
+        if t_emb is not None:
+            t_emb = _lib.dev_f32(t_emb, "ts[0]", 1 + 2 * Lt).reshape(-1, 1 + 2 * Lt)
+        _lib.check(_lib.lib().swnerf_mlp_forward(kind, _lib.ptr(packed), _lib.ptr(flat), M, Lp, Ld, _lib.ptr(t_emb), Lt,
+                                                 int(run_deform), _lib.ptr(out), _lib.ptr(dx), _lib.stream_of(x)),
+                   "mlp_forward")
+        out = _tag_no_backward(out.reshape(*lead, 4), self)
+        return out, (dx.reshape(*lead, 3) if want_dx else None)
+
+
+def _build_layers(mod, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, output_color_ch=3):
+    mod.pts_linears = nn.ModuleList(
+        [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W) for i in range(D - 1)])
+    mod.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+    if use_viewdirs:
+        mod.feature_linear = nn.Linear(W, W)
+        mod.alpha_linear = nn.Linear(W, 1)
+        mod.rgb_linear = nn.Linear(W // 2, output_color_ch)
+    else:
+        mod.output_linear = nn.Linear(W, output_ch)
+
+
+class vallina_NeRF(nn.Module, _PackedMixin):
+    """model.py:10-62."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        _build_layers(self, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs)
+        self._init_pack()
+
+    def _pack_params(self):
+        Lp, Ld = self._check_arch()
+        return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
+
+    def forward(self, x):
+        return self._forward_hip(x)[0]
+
+
+class NeRFOriginal(nn.Module, _PackedMixin):
+    """model.py:227-296: same network, kaiming-normal weights, returns (out, zeros[M,3])."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_time=1, output_ch=4, skips=[4],
+                 use_viewdirs=False, memory=[], embed_fn=None, output_color_ch=3, zero_canonical=True):
+        super().__init__()
+        if any(i in memory for i in range(D - 1)):
+            raise NotImplementedError                                   # model.py:243-244
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        _build_layers(self, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, output_color_ch)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in')  # model.py:270-272
+        self._init_pack()
+
+    def _pack_params(self):
+        Lp, Ld = self._check_arch()
+        return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
+
+    def forward(self, x, ts):
+        out, _ = self._forward_hip(x)
+        return out, torch.zeros_like(x[..., :3])
+
+
+class DirectTemporalNeRF(nn.Module, _PackedMixin):
+    """model.py:93-151: deformation net `_time`/`_time_out`, then the canonical `_occ`."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_time=1, output_ch=4, skips=[4],
+                 use_viewdirs=False, memory=[], embed_fn=None, zero_canonical=True):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.input_ch_time, self.skips, self.use_viewdirs = input_ch_time, skips, use_viewdirs
+        self.memory, self.embed_fn, self.zero_canonical = memory, embed_fn, zero_canonical
+        self._occ = NeRFOriginal(D=D, W=W, input_ch=input_ch, input_ch_views=input_ch_views,
+                                 input_ch_time=input_ch_time, output_ch=output_ch, skips=skips,
+                                 use_viewdirs=use_viewdirs, memory=memory, embed_fn=embed_fn, output_color_ch=3)
+        layers = [nn.Linear(input_ch + input_ch_time, W)]
+        for i in range(D - 1):
+            if i in memory:
+                raise NotImplementedError
+            layers.append(nn.Linear(W + input_ch if i in skips else W, W))
+        self._time = nn.ModuleList(layers)
+        self._time_out = nn.Linear(W, 3)
+        self._init_pack()
+
+    def _pack_params(self):
+        Lp, Ld = self._check_arch()
+        Lt = _bands(self.input_ch_time, 1)
+        if Lt is None or Lt > 10:
+            raise NotImplementedError(f"swnerf: input_ch_time={self.input_ch_time} must be 1+2L with L<=10")
+        emb = self.embed_fn
+        if emb is not None and getattr(emb, "multires", Lp) != Lp:
+            raise NotImplementedError("swnerf: DirectTemporalNeRF.embed_fn must be the get_embedder(multires, 3) "
+                                      "encoder matching input_ch (the kernel re-embeds x+dx itself, model.py:148-149)")
+        return _lib.NET_DNERF, ["_occ." + n for n in _CANON_ORDER] + _DEFORM_ORDER, Lp, Ld, Lt
+
+    def forward(self, x, ts):
+        t = ts[0]
+        # the reference asserts one unique time and branches on its value: two host syncs
+        # (model.py:141-144); one here
+        lo, hi = torch.aminmax(t[:, :1])
+        lo, hi = float(lo), float(hi)
+        assert lo == hi, "Only accepts all points from same time"
+        run_deform = not (lo == 0. and self.zero_canonical)
+        out, dx = self._forward_hip(x, t_emb=t, run_deform=run_deform, want_dx=True)
+        return out, dx
+
+
+class NeRF:
+    @staticmethod
+    def get_by_name(type, *args, **kwargs):
+        """model.py:214-225."""
+        print("NeRF type selected: %s" % type)
+        if type == "original":
+            return NeRFOriginal(*args, **kwargs)
+        if type == "direct_temporal":
+            return DirectTemporalNeRF(*args, **kwargs)
+        raise ValueError("Type %s not recognized." % type)

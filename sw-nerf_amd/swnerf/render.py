@@ -1,0 +1,288 @@
+"""Counterparts of the render functions of the reference's static-NeRF runner
+(nerf/run.py:63-219, 316-422): batchify, run_network, batchify_rays, render, render_path,
+render_rays - same names, arguments, dict keys and shapes.
+
+render_rays dispatches to the FUSED HIP pass (csrc/render_kernels.hip: one wavefront per
+ray, sampling -> encoding -> MLP -> compositing -> resampling without touching HBM) when
+`network_fn` is a swnerf module and the `network_query_fn` closure carries the standard
+get_embedder encoders; otherwise it runs the reference's op sequence on the individual HIP
+ops (embed / mlp_forward / raw2outputs / sample_pdf)."""
+import inspect
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ray import get_rays, ndc_rays, sample_pdf, raw2outputs, _device_of
+from .embedder import EmbedFn
+from .model import vallina_NeRF, NeRFOriginal, DirectTemporalNeRF
+
+DEBUG = False
+
+
+def batchify(fn, chunk):
+    """nerf/run.py:63-70."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """nerf/run.py:73-87."""
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+# ------------------------------------------------------------------------------ fused dispatch
+def closure_embedders(network_query_fn):
+    """The encoders inside the lambda that create_nerf builds (nerf/run.py:248-251,
+    d_nerf/run_dnerf.py:281-286), or an explicit `.swnerf_embedders` dict on the callable."""
+    tagged = getattr(network_query_fn, "swnerf_embedders", None)
+    if tagged is not None:
+        return dict(tagged)
+    try:
+        nl = inspect.getclosurevars(network_query_fn).nonlocals
+    except TypeError:
+        return {}
+    return {k: nl[k] for k in ("embed_fn", "embeddirs_fn", "embedtime_fn") if k in nl}
+
+
+def fused_plan(network_query_fn, nets, need_time=False):
+    """Returns (L_pos, L_dir, L_time) when every net is a swnerf module on the GPU and the
+    closure's encoders are the standard ones matching the nets' input sizes; else None."""
+    emb = closure_embedders(network_query_fn)
+    ef, edf, etf = emb.get("embed_fn"), emb.get("embeddirs_fn"), emb.get("embedtime_fn")
+    if not (isinstance(ef, EmbedFn) and isinstance(edf, EmbedFn) and ef.input_dims == 3 and edf.input_dims == 3):
+        return None
+    if need_time and not (isinstance(etf, EmbedFn) and etf.input_dims == 1):
+        return None
+    Lt = etf.multires if need_time else 0
+    for net in nets:
+        if net is None:
+            continue
+        if not isinstance(net, (vallina_NeRF, NeRFOriginal, DirectTemporalNeRF)):
+            return None
+        if net.input_ch != ef.out_dim or net.input_ch_views != edf.out_dim:
+            return None
+        if isinstance(net, DirectTemporalNeRF) and (not need_time or net.input_ch_time != etf.out_dim):
+            return None
+    return ef.multires, edf.multires, Lt
+
+
+def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
+                want=("rgb_map", "disp_map", "acc_map"), n_importance=0, u=None, run_deform=True):
+    """One launch of `swnerf_render_pass` (include/swnerf.h).  Returns a dict of the requested
+    outputs among rgb_map disp_map acc_map depth_map weights raw dx z_out, plus z_fine/z_std
+    when n_importance > 0."""
+    kind, packed, Lp, Ld, Lt = net.packed()
+    rb = _lib.dev_f32(ray_batch, "ray_batch")
+    N, cols = rb.shape
+    S = int(n_samples)
+    dev = rb.device
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    shapes = {"rgb_map": (N, 3), "disp_map": (N,), "acc_map": (N,), "depth_map": (N,), "weights": (N, S),
+              "raw": (N, S, 4), "dx": (N, S, 3), "z_out": (N, S)}
+    out = {k: new(*shapes[k]) for k in want}
+    a = _lib.PassArgs()
+    a.ray_batch, a.n_rays, a.cols, a.kind, a.packed = rb.data_ptr(), N, cols, kind, packed.data_ptr()
+    a.run_deform, a.L_pos, a.L_dir, a.L_time, a.n_samples = int(bool(run_deform)), Lp, Ld, Lt, S
+    keep = [rb, packed]
+    for name, t, last in (("z_vals", z_vals, S), ("t_rand", t_rand, S), ("noise", noise, S), ("u", u, int(n_importance))):
+        if t is not None:
+            t = _lib.dev_f32(t, name, last)
+            if t.shape[0] != N:
+                raise ValueError(f"swnerf.render_pass: {name} must have {N} rows, got {tuple(t.shape)}")
+            keep.append(t)
+            setattr(a, name, t.data_ptr())
+    a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+    for k, t in out.items():
+        setattr(a, k, t.data_ptr())
+    a.n_importance = int(n_importance)
+    if n_importance > 0:
+        out["z_fine"] = new(N, S + int(n_importance))
+        out["z_std"] = new(N)
+        a.z_fine, a.z_std = out["z_fine"].data_ptr(), out["z_std"].data_ptr()
+    _lib.check(_lib.lib().swnerf_render_pass(a, _lib.stream_of(rb)), "render_pass")
+    return out
+
+
+def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev):
+    """The three random tensors of render_rays (nerf/run.py:375-381, ray.py:117-132, :176-184)."""
+    t_rand = u = None
+    if perturb > 0.:
+        t_rand = torch.rand((N, N_samples), device=dev)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(N, N_samples)).to(dev)
+        if N_importance > 0:
+            u = torch.rand((N, N_importance), device=dev)
+            if pytest:
+                np.random.seed(0)
+                u = torch.Tensor(np.random.rand(N, N_importance)).to(dev)
+
+    def noise(S):
+        if not raw_noise_std > 0.:
+            return None
+        if pytest:
+            np.random.seed(0)
+            return torch.Tensor(np.random.rand(N, S) * raw_noise_std).to(dev)
+        return torch.randn((N, S), device=dev) * raw_noise_std
+    return t_rand, u, noise
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
+    """nerf/run.py:316-422."""
+    plan = fused_plan(network_query_fn, [network_fn, network_fine]) if ray_batch.shape[-1] == 11 else None
+    if plan is None:
+        return _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb,
+                                    N_importance, network_fine, white_bkgd, raw_noise_std, pytest)
+    N = ray_batch.shape[0]
+    t_rand, u, noise = _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
+    want = ["rgb_map", "disp_map", "acc_map"] + (["raw"] if (retraw and N_importance <= 0) else [])
+    p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
+                     white_bkgd=white_bkgd, want=want, n_importance=max(0, N_importance), u=u)
+    if N_importance <= 0:
+        ret = {'rgb_map': p0["rgb_map"], 'disp_map': p0["disp_map"], 'acc_map': p0["acc_map"]}
+        if retraw:
+            ret['raw'] = p0["raw"]
+        return ret
+    S1 = N_samples + N_importance
+    run_fn = network_fn if network_fine is None else network_fine
+    p1 = render_pass(ray_batch, run_fn, S1, z_vals=p0["z_fine"], noise=noise(S1), white_bkgd=white_bkgd,
+                     want=["rgb_map", "disp_map", "acc_map"] + (["raw"] if retraw else []))
+    ret = {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"]}
+    if retraw:
+        ret['raw'] = p1["raw"]
+    ret['rgb0'], ret['disp0'], ret['acc0'] = p0["rgb_map"], p0["disp_map"], p0["acc_map"]
+    ret['z_std'] = p0["z_std"]
+    return ret
+
+
+def _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest):
+    """nerf/run.py:361-383 with torch ops (unfused path only)."""
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=near.device)
+    z_vals = near * (1. - t_vals) + far * t_vals if not lindisp else 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    z_vals = z_vals.expand([N_rays, N_samples])
+    if perturb > 0.:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        t_rand = torch.rand(z_vals.shape, device=near.device)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(*list(z_vals.shape))).to(near.device)
+        z_vals = lower + (upper - lower) * t_rand
+    return z_vals
+
+
+def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb, N_importance,
+                         network_fine, white_bkgd, raw_noise_std, pytest):
+    """The reference's op sequence (nerf/run.py:354-416) on the individual HIP ops; taken when the
+    nets / encoders are not the ones the fused pass is built for."""
+    N_rays = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
+    near, far = bounds[..., 0], bounds[..., 1]
+    z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
+        z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest).detach()
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'], ret['disp0'], ret['acc0'] = rgb_map_0, disp_map_0, acc_map_0
+        ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """nerf/run.py:90-102.  (The fused pass needs no chunking for memory - activations never
+    reach HBM - but `chunk` is honoured so results are laid out the same way.)"""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+
+def pack_ray_batch(rays_o, rays_d, near, far, frame_time=None, ndc=False, H=0, W=0, focal=1.):
+    """rows [o d near far (t) viewdirs] - nerf/run.py:137-158 / d_nerf/run_dnerf.py:137-160."""
+    rays_d = _lib.dev_f32(torch.reshape(rays_d, [-1, 3]), "rays_d", 3)
+    rays_o = _lib.dev_f32(torch.reshape(rays_o.expand(rays_d.shape) if rays_o.numel() != rays_d.numel() else rays_o, [-1, 3]), "rays_o", 3)
+    n = rays_d.shape[0]
+    scalar = lambda v: not isinstance(v, (torch.Tensor, np.ndarray))
+    cols = 12 if frame_time is not None else 11
+    out = torch.empty((n, cols), dtype=torch.float32, device=rays_d.device)
+    _lib.check(_lib.lib().swnerf_pack_ray_batch(
+        _lib.ptr(rays_o), _lib.ptr(rays_d), n, float(near) if scalar(near) else 0., float(far) if scalar(far) else 0.,
+        int(frame_time is not None), float(frame_time) if (frame_time is not None and scalar(frame_time)) else 0.,
+        int(bool(ndc)), int(H), int(W), float(focal), _lib.ptr(out), _lib.stream_of(out)), "pack_ray_batch")
+    for col, v in ((6, near), (7, far), (8, frame_time)):       # per-ray arrays (render() docstring) via torch
+        if v is not None and not scalar(v):
+            out[:, col] = torch.as_tensor(v, dtype=torch.float32, device=out.device).reshape(-1)
+    return out
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """nerf/run.py:105-169 -> [rgb_map, disp_map, acc_map, extras]."""
+    if not use_viewdirs:
+        raise NotImplementedError("swnerf.render: only use_viewdirs=True is built (every shipped config sets it)")
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    viewsrc = rays_d
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+    sh = rays_d.shape
+    if c2w_staticcam is not None:
+        # view directions from c2w, geometry from the static camera (nerf/run.py:139-142)
+        vb = pack_ray_batch(rays_o, viewsrc, near, far)
+        rb = pack_ray_batch(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=K[0][0])
+        rb[:, -3:] = vb[:, -3:]
+    else:
+        rb = pack_ray_batch(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=K[0][0])
+    all_ret = batchify_rays(rb, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """nerf/run.py:172-219 (image files are the caller's business: `savedir` is not supported here)."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    if savedir is not None:
+        raise NotImplementedError("swnerf.render_path: writing PNGs is outside the render path (SURVEY.md 8f rank 3)")
+    rgbs, disps = [], []
+    for c2w in render_poses:
+        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+    return np.stack(rgbs, 0), np.stack(disps, 0)
