@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) get_rays_kernel(Cam c, int W, int64_t ray
 
 extern "C" int swnerf_get_rays(int H, int W, double fx, double fy, double cx, double cy, int focal_branch,
                                const float* c2w, int64_t ray0, int64_t n, float* rays_o, float* rays_d, void* stream) {
+    if (n == 0 && H > 0 && W > 0) return 0;
     if (!c2w || !rays_d || H <= 0 || W <= 0 || n < 0 || ray0 < 0 || ray0 + n > (int64_t)H * W)
         return sw_fail(SWNERF_E_ARG, "get_rays: bad arguments (H=%d W=%d ray0=%lld n=%lld)", H, W, (long long)ray0, (long long)n);
     Cam c;
@@ -70,8 +71,8 @@ static inline float ndc_scale(int WH, double focal) { return (float)(-1. / (WH /
 
 extern "C" int swnerf_ndc_rays(int H, int W, double focal, double near, const float* rays_o, const float* rays_d,
                                int64_t n, float* o_out, float* d_out, void* stream) {
-    if (!rays_o || !rays_d || !o_out || !d_out || n < 0) return sw_fail(SWNERF_E_ARG, "ndc_rays: NULL pointer / negative n");
     if (n == 0) return 0;
+    if (!rays_o || !rays_d || !o_out || !d_out || n < 0) return sw_fail(SWNERF_E_ARG, "ndc_rays: NULL pointer / negative n");
     hipLaunchKernelGGL(ndc_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        ndc_scale(W, focal), ndc_scale(H, focal), (float)near, rays_o, rays_d, n, o_out, d_out);
     return sw_check(hipGetLastError(), "ndc_rays launch");
@@ -97,8 +98,8 @@ __global__ void __launch_bounds__(256) pack_rays_kernel(const float* ro, const f
 extern "C" int swnerf_pack_ray_batch(const float* rays_o, const float* rays_d, int64_t n, double near, double far,
                                      int has_time, double frame_time, int ndc, int H, int W, double ndc_focal,
                                      float* ray_batch, void* stream) {
-    if (!rays_o || !rays_d || !ray_batch || n < 0) return sw_fail(SWNERF_E_ARG, "pack_ray_batch: NULL pointer / negative n");
     if (n == 0) return 0;
+    if (!rays_o || !rays_d || !ray_batch || n < 0) return sw_fail(SWNERF_E_ARG, "pack_ray_batch: NULL pointer / negative n");
     const float sx = ndc ? ndc_scale(W, ndc_focal) : 0.f, sy = ndc ? ndc_scale(H, ndc_focal) : 0.f;
     hipLaunchKernelGGL(pack_rays_kernel, dim3(nblocks(n, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, n,
                        (float)near, (float)far, has_time, (float)frame_time, ndc, sx, sy, ray_batch);
@@ -123,10 +124,10 @@ __global__ void __launch_bounds__(256) embed_kernel(const float* x, int64_t tota
 }
 
 extern "C" int swnerf_embed(const float* x, int64_t M, int d, int L, float* out, void* stream) {
+    if (M == 0 && d > 0 && L >= 0) return 0;
     if (!x || !out || M < 0 || d <= 0 || L < 0 || L > 24) return sw_fail(SWNERF_E_ARG, "embed: bad arguments (M=%lld d=%d L=%d)", (long long)M, d, L);
     const int C = d * (1 + 2 * L);
     const int64_t total = M * C;
-    if (total == 0) return 0;
     hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total, 256)), dim3(256), 0, (hipStream_t)stream, x, total, d, C, out);
     return sw_check(hipGetLastError(), "embed launch");
 }
@@ -190,8 +191,9 @@ __global__ void __launch_bounds__(256) raw2outputs_kernel(const float* raw, cons
 extern "C" int swnerf_raw2outputs(const float* raw, const float* z_vals, const float* rays_d, const float* noise, int64_t N, int S,
                                   int white_bkgd, float* rgb_map, float* disp_map, float* acc_map, float* weights,
                                   float* depth_map, void* stream) {
-    if (!raw || !z_vals || !rays_d || N < 0 || S < 1) return sw_fail(SWNERF_E_ARG, "raw2outputs: bad arguments (N=%lld S=%d)", (long long)N, S);
-    if (N == 0) return 0;
+    if (S == 1) return sw_fail(SWNERF_E_UNSUPP, "raw2outputs: S=1 is degenerate in the reference (ray.py:170-171 builds an EMPTY dists tensor); need S>=2");
+    if (N == 0 && S >= 2) return 0;
+    if (!raw || !z_vals || !rays_d || N < 0 || S < 2) return sw_fail(SWNERF_E_ARG, "raw2outputs: bad arguments (N=%lld S=%d)", (long long)N, S);
     hipLaunchKernelGGL(raw2outputs_kernel, dim3(nblocks(N, 4)), dim3(256), 0, (hipStream_t)stream, raw, z_vals, rays_d, noise, N, S,
                        white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map);
     return sw_check(hipGetLastError(), "raw2outputs launch");
@@ -210,10 +212,13 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(const float* bins, const
     const float* b = bins + ray * nb;
     const float* w = wts + ray * (nb - 1);
     const int nw = nb - 1;
-    float part = 0.f;
-    for (int i = lane; i < nw; i += 64) part += w[i] + 1e-5f;
+    // sum(weights + 1e-5): accumulated in double and rounded once - the closest any order can get
+    // to ATen's float sum (whose own blocking is machine dependent); see DESIGN.md "conditioning"
+    double dpart = 0.0;
+    for (int i = lane; i < nw; i += 64) dpart += (double)(w[i] + 1e-5f);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    for (int o = 32; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 64);
+    const float part = (float)dpart;
     double carry = 0.0;
     for (int base = 0; base < nw; base += 64) {
         const int i = base + lane;
@@ -273,6 +278,7 @@ __global__ void __launch_bounds__(64) sample_pdf_kernel(const float* bins, const
 
 extern "C" int swnerf_sample_pdf(const float* bins, const float* weights, int64_t N, int nb, int n_samples, const float* u,
                                  float* samples, const float* z_vals, int S, float* z_sorted, float* z_std, void* stream) {
+    if (N == 0 && nb >= 2 && n_samples >= 1) return 0;
     if (!bins || !weights || !samples || N < 0 || nb < 2 || n_samples < 1)
         return sw_fail(SWNERF_E_ARG, "sample_pdf: bad arguments (N=%lld nb=%d n_samples=%d)", (long long)N, nb, n_samples);
     if (nb > SP_MAX_BINS) return sw_fail(SWNERF_E_UNSUPP, "sample_pdf: at most %d bins", SP_MAX_BINS);

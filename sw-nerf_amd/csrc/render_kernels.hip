@@ -178,11 +178,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; then sort (nerf/run.py:396-400)
     wave_lds_sync();
     const int nb = S - 1, nw = S - 2, Ni = a.n_importance;
-    float part = 0.f;
-    for (int i = lane; i < nw; i += 64) part += wc[i + 1] + 1e-5f;
+    double dpart = 0.0;                              // rounded once: see misc_kernels.hip sample_pdf_kernel
+    for (int i = lane; i < nw; i += 64) dpart += (double)(wc[i + 1] + 1e-5f);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    const float wsum = part;
+    for (int o = 32; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 64);
+    const float wsum = (float)dpart;
     double carry = 0.0;
     for (int base = 0; base < nw; base += 64) {      // cumsum accumulates in double like ATen's CPU kernel
         const int i = base + lane;
@@ -327,7 +327,7 @@ static int stream_ptrs(int kind, const float* packed, int run_deform, const floa
 extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (!args) return sw_fail(SWNERF_E_ARG, "render_pass: NULL args");
     const swnerf_pass_args& a = *args;
-    if (!a.ray_batch || !a.packed) return sw_fail(SWNERF_E_ARG, "render_pass: NULL ray_batch/packed");
+    if (!a.packed || (!a.ray_batch && a.n_rays != 0)) return sw_fail(SWNERF_E_ARG, "render_pass: NULL ray_batch/packed");
     if (a.n_rays < 0 || a.n_samples < 2) return sw_fail(SWNERF_E_ARG, "render_pass: n_rays %lld, n_samples %d", (long long)a.n_rays, a.n_samples);
     if (a.cols != 11 && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: ray_batch must have 11 or 12 columns (use_viewdirs), got %d", a.cols);
     if (a.kind == SWNERF_NET_DNERF && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: D-NeRF needs the frame_time column");
@@ -341,7 +341,7 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     P.sort_n = 0;
     size_t lds = 0;
     if (a.n_importance > 0) {
-        if (!a.z_fine) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
+        if (!a.z_fine && a.n_rays != 0) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
         if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
             return sw_fail(SWNERF_E_UNSUPP, "render_pass: resampling supports 3<=N_samples<=%d and N_samples+N_importance<=%d", SW_LDS_SC, SW_LDS_SORT);
         int p2 = 2;
@@ -359,6 +359,7 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
 
 extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
                                   const float* t_emb, int L_time, int run_deform, float* out, float* dx_out, void* stream) {
+    if (M == 0 && packed) return 0;
     if (!packed || !x || !out || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_forward: NULL pointer or negative M");
     if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4 || L_time < 0 || L_time > 10)
         return sw_fail(SWNERF_E_UNSUPP, "mlp_forward: embedder bands (%d,%d,%d) exceed (10,4,10)", L_pos, L_dir, L_time);
