@@ -13,7 +13,9 @@
 // Weights stream from L2 in "steps" of 1 KiB (4 MFMAs' A operands, one global_load_dwordx4
 // per lane) through a ring of SW_RING steps kept in flight; the ring never drains between
 // layers because the packed blob is laid out in execution order and ends with a copy of its
-// own first SW_RING steps.
+// own first SW_RING steps.  Biases (<= 18 KB per net) are copied to LDS once per workgroup.
+// LDS per workgroup: bias 18 KiB + 4 waves x SW_RING KiB of weight ring (+ 28 KiB of resampling
+// scratch in the render kernel).
 //
 // Reference arithmetic: model.py:39-62 (vallina_NeRF.forward), :273-296 (NeRFOriginal),
 // :128-151 (DirectTemporalNeRF.query_time / forward).
@@ -24,24 +26,99 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The weight ring lives in LDS and is filled by LDS-DMA (`global_load_lds_dwordx4`: global ->
+// LDS with no VGPR destination): each wave owns SW_RING slots of 1 KiB and keeps SW_RING-1
+// steps in flight.  Why not a register ring: hipcc (ROCm 7.2) sinks plain prefetch loads next
+// to their use under this kernel's register pressure (load -> vmcnt(0) -> 4 MFMA, one exposed
+// L2 round trip per step: 51 % of roofline), and inline-asm register loads are unsafe because
+// the compiler copies/spills their destination VGPRs at phi merges while the data is still in
+// flight (found by tools/isa_audit.py).  With LDS-DMA nothing the compiler can touch is ever
+// pending: the DMA issue and the counted `s_waitcnt vmcnt(N)` are `asm volatile` with a memory
+// clobber (so the compiler's own ds_read of a slot stays behind the wait that retires it),
+// and the A operands reach the MFMAs through ordinary ds_read_b128 issued ONE STEP AHEAD, which
+// the compiler tracks with lgkmcnt itself.  vmcnt retires in issue order and counts every VMEM
+// op, so compiler-issued loads/stores in between only make a wait more conservative.
+// Biases come from LDS too, so the hot loop's VMEM queue holds nothing but the DMA stream.
 struct WStream {
-    const f32x4* p;          // this lane's slot of the CURRENT step
-    f32x4 ring[SW_RING];     // steps [cur, cur + SW_RING)
-    const f32x4* bias;       // this lane-half's 16 biases of the CURRENT output tile
+    const char* base;        // wave-uniform: global byte address of the CURRENT step (SGPR pair)
+    unsigned voff;           // lane * 16
+    unsigned lds_addr;       // wave-uniform: LDS byte address of this wave's ring slot 0 (for M0)
+    const float* ring;       // the same ring as a pointer, + lane*4 floats (for ds_read_b128)
+    f32x4 a_cur;             // A operands of the CURRENT step (already read from LDS)
+    const float* bias;       // LDS: this lane-half's 16 biases of the CURRENT output tile
 };
 
-__device__ __forceinline__ void ws_start(WStream& ws, const float* w, const float* bias, int lane) {
-    ws.p = reinterpret_cast<const f32x4*>(w) + lane;
-    ws.bias = reinterpret_cast<const f32x4*>(bias) + (lane >> 5) * 4;
-#pragma unroll
-    for (int i = 0; i < SW_RING; ++i) ws.ring[i] = ws.p[i * 64];
+// one 1-KiB step: global [gbase + lane*16] -> LDS [lds_addr + lane*16].  M0 carries the LDS
+// base; it is compiler-reserved, so it is saved and restored inside the statement.
+// Write-after-read on the slot: seg_steps issues the DMA (pinned by sched_barrier) AFTER the
+// MFMAs that consumed the slot's previous contents, so that ds_read has returned.
+__device__ __forceinline__ void ws_dma(const char* gbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
 }
 
-// after the last segment of a stream the ring already holds the blob's tail copy of the
-// first SW_RING steps: rewind the pointers only.
-__device__ __forceinline__ void ws_rewind(WStream& ws, const float* w, const float* bias, int lane) {
-    ws.p = reinterpret_cast<const f32x4*>(w) + lane;
-    ws.bias = reinterpret_cast<const f32x4*>(bias) + (lane >> 5) * 4;
+template <int N>
+__device__ __forceinline__ void ws_wait() {      // all but the N youngest VMEM ops have landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+__device__ __forceinline__ f32x4 ws_read(const WStream& ws, int slot) {
+    return *reinterpret_cast<const f32x4*>(ws.ring + slot * SW_STEP_FLOATS);
+}
+
+template <int I>
+__device__ __forceinline__ void ws_prime(WStream& ws) {
+    if constexpr (I < SW_RING) {
+        ws_dma(ws.base + I * 1024, ws.voff, ws.lds_addr + I * 1024);
+        ws_prime<I + 1>(ws);
+    }
+}
+
+// lds_ring: this wave's SW_RING KiB of LDS
+__device__ __forceinline__ void ws_start(WStream& ws, const float* w, const float* lds_bias, float* lds_ring, int lane) {
+    ws.base = reinterpret_cast<const char*>(w);
+    ws.voff = (unsigned)lane * 16u;
+    ws.lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_ring);
+    ws.ring = lds_ring + lane * 4;
+    ws.bias = lds_bias + (lane >> 5) * 16;
+    ws_prime<0>(ws);
+    ws_wait<SW_RING - 1>();
+    ws.a_cur = ws_read(ws, 0);
+}
+
+// after the last segment of a stream the ring (and a_cur) already hold the blob's tail copy of
+// the first SW_RING steps: rewind the pointers only.
+__device__ __forceinline__ void ws_rewind(WStream& ws, const float* w, const float* lds_bias, int lane) {
+    ws.base = reinterpret_cast<const char*>(w);
+    ws.bias = lds_bias + (lane >> 5) * 16;
+}
+
+template <int S, int NS, int NT, int KT>
+__device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws) {
+    if constexpr (S < NS) {
+        constexpr int n = S / (KT * 4), kt = (S / 4) % KT, q = S % 4;
+        constexpr int slot = S % SW_RING, nslot = (S + 1) % SW_RING;
+        // steps S+1 .. S+SW_RING-1 are in flight: retire the oldest and read it one step ahead
+        ws_wait<SW_RING - 2>();
+        const f32x4 a_next = ws_read(ws, nslot);
+        __builtin_amdgcn_sched_barrier(0);       // keep the ds_read AHEAD of this step's MFMAs
+        const f32x4 a = ws.a_cur;
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], kin[kt][4 * q + 0], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], kin[kt][4 * q + 1], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], kin[kt][4 * q + 2], out[n], 0, 0, 0);
+        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], kin[kt][4 * q + 3], out[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);       // ... and the refill BEHIND them (WAR on the slot)
+        // refill the slot of step S (read during step S-1) with step S + SW_RING
+        ws_dma(ws.base + (S + SW_RING) * 1024, ws.voff, ws.lds_addr + slot * 1024);
+        ws.a_cur = a_next;
+        seg_steps<S + 1, NS, NT, KT>(out, kin, ws);
+    }
 }
 
 // out[n] (+)= sum_kt  Wtile(n,kt) . kin[kt]       NT output tiles, KT input tiles.
@@ -55,24 +132,22 @@ __device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b = ws.bias[n * 8 + g];
+                const f32x4 b = *reinterpret_cast<const f32x4*>(ws.bias + n * SW_BIAS_TILE_FLOATS + 4 * g);
                 out[n][4 * g + 0] = b[0]; out[n][4 * g + 1] = b[1];
                 out[n][4 * g + 2] = b[2]; out[n][4 * g + 3] = b[3];
             }
         }
-        ws.bias += NT * 8;
+        ws.bias += NT * SW_BIAS_TILE_FLOATS;
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int n = s / (KT * 4), kt = (s / 4) % KT, q = s % 4;
-        const f32x4 a = ws.ring[s % SW_RING];
-        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], kin[kt][4 * q + 0], out[n], 0, 0, 0);
-        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], kin[kt][4 * q + 1], out[n], 0, 0, 0);
-        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], kin[kt][4 * q + 2], out[n], 0, 0, 0);
-        out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], kin[kt][4 * q + 3], out[n], 0, 0, 0);
-        ws.ring[s % SW_RING] = ws.p[(s + SW_RING) * 64];
-    }
-    ws.p += NS * 64;
+    seg_steps<0, NS, NT, KT>(out, kin, ws);
+    ws.base += NS * 1024;
+}
+
+// cooperative copy of a bias stream into LDS (whole block; ends with a barrier)
+__device__ __forceinline__ void bias_to_lds(float* lds_bias, const float* gbias, int nfloats) {
+    for (int i = threadIdx.x * 4; i < nfloats; i += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(lds_bias + i) = *reinterpret_cast<const f32x4*>(gbias + i);
+    __syncthreads();
 }
 
 // ---- positional encodings into B-operand slots (slot maps: swnerf_common.h) --------------

@@ -22,9 +22,13 @@ struct PassDev {
     swnerf_pass_args a;
     const float* w0;        // weight stream this pass runs per tile
     const float* b0;        // its bias stream
+    int nbias;              // floats in the bias stream (multiple of 32)
     int two_pass;           // 1: deformation net then canonical net
     int sort_n;             // power of two >= S + n_importance
 };
+#define SW_LDS_BIAS_FLOATS ((SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
+#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS)            // per wave
+#define SW_LDS_FIXED_FLOATS (SW_LDS_BIAS_FLOATS + 4 * SW_LDS_RING_FLOATS)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -63,8 +67,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-    if (ray >= a.n_rays) return;                 // wave-uniform; the kernel has no block barrier
-    float* lds = lds_all + wv * SW_LDS_WAVE_FLOATS;
+    bias_to_lds(lds_all, P.b0, P.nbias);         // the only block barrier; waves are independent after it
+    if (ray >= a.n_rays) return;                 // wave-uniform
+    const float* lds_bias = lds_all;
+    float* lds_ring = lds_all + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds = lds_all + SW_LDS_FIXED_FLOATS + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
     float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
     float* cdf = lds + 2 * SW_LDS_SC;            // [S-1]
@@ -80,7 +87,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
 
     WStream ws;
-    ws_start(ws, P.w0, P.b0, lane);
+    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
     double Tc = 1.0;                              // transmittance carried across tiles
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
         }
         canon_tail(in, out, v0, v1, v2, h, rgb, ws);
-        ws_rewind(ws, P.w0, P.b0, lane);
+        ws_rewind(ws, P.w0, lds_bias, lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
         const float c0 = __shfl(rgb[0], j), c1 = __shfl(rgb[1], j), c2 = __shfl(rgb[2], j);
@@ -249,7 +256,7 @@ struct MlpDev {
     const float* x; int64_t M; int C;   // C = C_pos + C_dir
     int Lp, Ld, Lt, Cpos;
     const float* t_emb; int Ct;
-    const float* w0; const float* b0; int two_pass;
+    const float* w0; const float* b0; int nbias; int two_pass;
     float* out; float* dx;
 };
 
@@ -257,7 +264,10 @@ template <bool DNERF>
 __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
+    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_bias, P.b0, P.nbias);
     if (tile * 32 >= P.M) return;
     const int64_t row = tile * 32 + j;
     const bool live = row < P.M;
@@ -270,7 +280,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
         emb[a >> 4][a & 15] = (col >= 0) ? xr[col] : 0.f;
     }
     WStream ws;
-    ws_start(ws, P.w0, P.b0, lane);
+    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
     float ex = 0.f, ey = 0.f, ez = 0.f;
     if (DNERF) {
         const float ft = P.t_emb ? P.t_emb[(live ? row : P.M - 1) * P.Ct] : 0.f;   // column 0 of gamma(t) is t
@@ -312,11 +322,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
 }
 
 // ------------------------------------------------------------------------------------------
-static int stream_ptrs(int kind, const float* packed, int run_deform, const float** w0, const float** b0, int* two) {
+static int stream_ptrs(int kind, const float* packed, int run_deform, const float** w0, const float** b0, int* nbias, int* two) {
+    *nbias = SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
     if (kind == SWNERF_NET_CANON) {
         *w0 = packed; *b0 = packed + SW_CANON_W_FLOATS; *two = 0;
     } else if (kind == SWNERF_NET_DNERF) {
-        if (run_deform) { *w0 = packed; *b0 = packed + SW_DNERF_W_FLOATS; *two = 1; }
+        if (run_deform) { *w0 = packed; *b0 = packed + SW_DNERF_W_FLOATS; *two = 1; *nbias = SW_LDS_BIAS_FLOATS; }
         else { const float* c = packed + SW_DNERF_A_FLOATS; *w0 = c; *b0 = c + SW_CANON_W_FLOATS; *two = 0; }
     } else {
         return sw_fail(SWNERF_E_ARG, "unknown net kind %d", kind);
@@ -336,10 +347,10 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (a.z_vals && a.t_rand) return sw_fail(SWNERF_E_ARG, "render_pass: t_rand only applies to coarse sampling");
     PassDev P;
     P.a = a;
-    int rc = stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.two_pass);
+    int rc = stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
     P.sort_n = 0;
-    size_t lds = 0;
+    size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine && a.n_rays != 0) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
         if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
@@ -347,7 +358,7 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
         int p2 = 2;
         while (p2 < a.n_samples + a.n_importance) p2 <<= 1;
         P.sort_n = p2;
-        lds = 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
+        lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
     }
     if (a.n_rays == 0) return 0;
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
@@ -369,12 +380,12 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     P.Cpos = 3 * (1 + 2 * L_pos); P.C = P.Cpos + 3 * (1 + 2 * L_dir);
     P.t_emb = t_emb; P.Ct = 1 + 2 * L_time;
     P.out = out; P.dx = dx_out;
-    int rc = stream_ptrs(kind, packed, run_deform, &P.w0, &P.b0, &P.two_pass);
+    int rc = stream_ptrs(kind, packed, run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
-    if (M == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    if (kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(mlp_forward_kernel<true>, grid, block, 0, st, P);
-    else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, 0, st, P);
+    const size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
+    if (kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(mlp_forward_kernel<true>, grid, block, lds, st, P);
+    else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, lds, st, P);
     return sw_check(hipGetLastError(), "mlp_forward launch");
 }

@@ -19,6 +19,7 @@ from .embedder import EmbedFn
 from .model import vallina_NeRF, NeRFOriginal, DirectTemporalNeRF
 
 DEBUG = False
+PASS_HOOK = None     # bench.py: callable(phase, n_rays, n_samples) with phase in {"begin", "end"} around each launch
 
 
 def batchify(fn, chunk):
@@ -112,7 +113,11 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
         out["z_fine"] = new(N, S + int(n_importance))
         out["z_std"] = new(N)
         a.z_fine, a.z_std = out["z_fine"].data_ptr(), out["z_std"].data_ptr()
+    if PASS_HOOK is not None:
+        PASS_HOOK("begin", N, S)
     _lib.check(_lib.lib().swnerf_render_pass(a, _lib.stream_of(rb)), "render_pass")
+    if PASS_HOOK is not None:
+        PASS_HOOK("end", N, S)
     return out
 
 
