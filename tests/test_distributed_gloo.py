@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the ray-sharded path: contiguous shards, one
+all-gather of pixels, every rank ends with the full image.  The per-rank renderer is the CPU
+oracle here (no GPU in this container); on the GPU box the same parallel.* code runs over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "sw-nerf_amd"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from swnerf import parallel, synth
+    from oracle import nerf_oracle as O
+    H, W = 9, 14                                   # 126 rays: ragged over 2 (63/63) and over the 4 below
+    K, c2w = synth.lego_camera(H, W)
+    sd = O.to_torch_sd(synth.nerf_state_dict(*synth.NET_COARSE[:1], alpha_bias=synth.NET_COARSE[1]))
+    o, d = O.get_rays(H, W, K, c2w)
+    rb = O.make_ray_batch(o, d, 2., 6.)
+
+    def render_range(lo, n):
+        with torch.no_grad():
+            r = O.render_rays(rb[lo:lo + n], sd, None, 16, 0, white_bkgd=True)
+        return torch.cat([r["rgb_map"], r["disp_map"][:, None], r["acc_map"][:, None]], -1)
+
+    img = parallel.render_image_sharded(render_range, H, W)
+    # equal shards -> the single-collective path; ragged shards -> pad/trim path
+    a = torch.full((5, 3), float(rank))
+    same = parallel.gather_pixels(a)
+    rag = parallel.gather_pixels(torch.full((3 + rank, 2), float(rank)), counts=[3 + r for r in range(world)])
+    # the bench's timing reduction: MAX over ranks
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put((img.numpy(), render_range(0, H * W).reshape(H, W, 5).numpy(), same.numpy(), rag.numpy(), float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_render_gloo_world2():
+    world, port = 2, 29571
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    img, ref, same, rag, tmax = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert img.shape == (9, 14, 5)
+    np.testing.assert_allclose(img, ref, atol=2e-6, equal_nan=True)      # (sgemm blocking differs with the row count)
+    assert np.array_equal(same[:5], np.zeros((5, 3))) and np.array_equal(same[5:], np.ones((5, 3)))
+    assert rag.shape == (7, 2) and np.array_equal(rag[:3], np.zeros((3, 2))) and np.array_equal(rag[3:], np.ones((4, 2)))
+    assert tmax == 2.0

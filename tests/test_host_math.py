@@ -1,0 +1,60 @@
+"""Host-compiled (g++) checks of csrc/swnerf_common.h: the sin/cos used by every kernel, the
+linspace restatement, and that the embedding slot maps cover each reference column exactly once."""
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+SRC = r'''
+#include "swnerf_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+int main() {
+  double worst = 0; srand(3);
+  for (int it = 0; it < 3000000; ++it) {
+    float x = ((float)rand() / RAND_MAX * 2 - 1) * 6.0f; int k = rand() % 10; float y = x * (float)(1 << k);
+    for (int c = 0; c < 2; ++c) { double e = fabs((double)sw_sin_or_cos(y, c) - (c ? cos((double)y) : sin((double)y))); if (e > worst) worst = e; }
+  }
+  printf("%.6e\n", worst);
+  int sizes[] = {64, 128, 192, 100, 33, 2};
+  for (int s = 0; s < 6; ++s) { for (int i = 0; i < sizes[s]; ++i) printf("%.9g ", sw_linspace(0.f, 1.f, sizes[s], i)); printf("\n"); }
+  for (int L = 0; L <= 10; ++L) { for (int a = 0; a < 32; ++a) for (int h = 0; h < 2; ++h) printf("%d ", sw_pos_col(a, h, L)); printf("\n"); }
+  for (int L = 0; L <= 4; ++L) { for (int a = 0; a < 16; ++a) for (int h = 0; h < 2; ++h) printf("%d ", sw_dir_col(a, h, L)); printf("\n"); }
+  for (int L = 0; L <= 10; ++L) { for (int a = 0; a < 16; ++a) for (int h = 0; h < 2; ++h) printf("%d ", sw_time_col(a, h, L)); printf("\n"); }
+  for (int h = 0; h < 2; ++h) { for (int r = 0; r < 16; ++r) printf("%d ", sw_frow(r, h)); printf("\n"); }
+  printf("%d %d %d %d\n", SW_CANON_STEPS, SW_DEFORM_STEPS, SW_CANON_FLOATS, SW_DNERF_FLOATS);
+  return 0;
+}
+'''
+
+
+def test_common_header_on_host(tmp_path):
+    (tmp_path / "t.cpp").write_text(SRC)
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-mfma", "-I", os.path.join(ROOT, "sw-nerf_amd", "csrc"),
+                    str(tmp_path / "t.cpp"), "-o", str(tmp_path / "t"), "-lm"], check=True)
+    lines = subprocess.run([str(tmp_path / "t")], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+    assert float(lines[0]) < 1.2e-7                                   # max |err| of sin/cos vs double libm, |y| <= 3072
+    for ln, n in zip(lines[1:7], (64, 128, 192, 100, 33, 2)):         # == torch.linspace on CPU, bit for bit
+        assert np.array_equal(np.array(ln.split(), np.float32), torch.linspace(0., 1., n).numpy())
+    k = 7
+    for L in range(11):                                               # every column of gamma(x), once
+        cols = [int(c) for c in lines[k + L].split() if int(c) >= 0]
+        assert sorted(cols) == list(range(3 * (1 + 2 * L)))
+    k += 11
+    for L in range(5):
+        cols = [int(c) for c in lines[k + L].split() if int(c) >= 0]
+        assert sorted(cols) == list(range(3 * (1 + 2 * L)))
+    k += 5
+    for L in range(11):
+        cols = [int(c) for c in lines[k + L].split() if int(c) >= 0]
+        assert sorted(cols) == list(range(1 + 2 * L))
+    k += 11
+    rows = [int(c) for c in (lines[k] + " " + lines[k + 1]).split()]
+    assert sorted(rows) == list(range(32))                            # the MFMA C/D map is a bijection onto the tile rows
+    canon, deform, cf, df = (int(x) for x in lines[k + 2].split())
+    # 4 MFMAs per step, 2048 MACs per MFMA on a 32-row tile: >= the algorithmic MACs, padding <= 3 %
+    assert canon * 4 * 2048 >= 593408 * 32 and canon * 4 * 2048 <= 1.03 * 593408 * 32
+    assert deform * 4 * 2048 >= 497152 * 32 and deform * 4 * 2048 <= 1.03 * 497152 * 32
+    assert canon % 8 == 0 and deform % 8 == 0

@@ -63,8 +63,8 @@ def audit(body):
                     bad.append((ln, line, sorted(used & regs), at))
         if VMEM.match(op):
             dest = set()
-            if 'load' in op:
-                dest = vregs(line.split(',')[0])
+            if 'load' in op and '_lds_' not in op and not line.rstrip().endswith(' lds'):
+                dest = vregs(line.split(',')[0])       # (LDS-DMA has no register destination)
             pending.append((in_asm, dest if in_asm else set(), ln))
             if in_asm:
                 stats['ring_loads'] += 1
