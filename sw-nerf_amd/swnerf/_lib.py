@@ -39,6 +39,10 @@ def lib():
         raise RuntimeError(
             f"swnerf: {LIB_PATH} not found - build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback for the render path")
+    # torch bundles its own libamdhip64/libhsa-runtime64; ours must bind to THAT copy (same SONAME), not
+    # pull /opt/rocm's into the process first - two HSA runtimes in one process cannot both own the GPU
+    # ("no ROCm-capable device is detected").  So: torch first, always.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.swnerf_version.restype = c_int
     L.swnerf_last_error.restype = c_char_p
