@@ -158,3 +158,27 @@ def g7_rand_inputs(n=256):
 
 def g8_inputs(n=512):
     return g7_inputs(n=n, seed=5)
+
+
+# ------------------------------------------------------------------ G9 cameras
+def g9_poses_bounds(n=11):
+    """A seeded LLFF `poses_bounds.npy` ([n,17]): forward-facing cameras jittered around the origin."""
+    rng = np.random.default_rng(109)
+    rows = []
+    for i in range(n):
+        ang = rng.normal(0, 0.08, 3)
+        cx, sx, cy, sy = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1])
+        R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        t = rng.normal(0, 0.6, 3) * np.array([1.0, 0.6, 0.15])
+        hwf = np.array([3024., 4032., 3260.5])
+        m = np.concatenate([R, t[:, None], hwf[:, None]], 1)          # [3,5]
+        rows.append(np.concatenate([m.reshape(-1), [rng.uniform(3.5, 5.0), rng.uniform(30., 80.)]]))
+    return np.array(rows, np.float64)
+
+
+def g9_blender_frames():
+    out = {}
+    for s, thetas in (("train", range(0, 360, 40)), ("val", range(10, 360, 90)), ("test", range(5, 360, 60))):
+        out[s] = [{"file_path": f"./{s}/r_{i}", "transform_matrix": synth.pose_spherical(float(t), -30.0 + i, 4.0).astype(float).tolist()}
+                  for i, t in enumerate(thetas)]
+    return out

@@ -1,0 +1,75 @@
+"""reference-format checkpoints load into the swnerf modules (and back)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from swnerf import checkpoint, model, synth
+
+REF = "/root/reference"
+
+
+def _nets():
+    mk = lambda: model.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    return mk(), mk()
+
+
+def test_roundtrip_and_discovery(tmp_path):
+    a, b = _nets()
+    opt = torch.optim.Adam(list(a.parameters()) + list(b.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    assert checkpoint.reload_latest(str(tmp_path), "exp", a, b, opt) == (0, None)
+    p1 = checkpoint.save_checkpoint(str(tmp_path), "exp", 10000, 10001, a, b, opt)
+    with torch.no_grad():
+        a.rgb_linear.bias.add_(1.0)
+    p2 = checkpoint.save_checkpoint(str(tmp_path), "exp", 20000, 20001, a, b, opt)
+    assert os.path.basename(p1) == "010000.tar" and checkpoint.find_checkpoints(str(tmp_path), "exp") == [p1, p2]
+    assert set(torch.load(p2, weights_only=False).keys()) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict"}
+    c, d = _nets()
+    step, path = checkpoint.reload_latest(str(tmp_path), "exp", c, d, None)
+    assert (step, path) == (20001, p2)
+    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), c.state_dict().values()))
+    assert checkpoint.reload_latest(str(tmp_path), "exp", c, d, None, no_reload=True) == (0, None)
+    assert checkpoint.reload_latest(str(tmp_path), "exp", c, d, None, ft_path=p1)[0] == 10001
+    assert checkpoint.to8b(np.array([-1., 0.5, 2.])).tolist() == [0, 127, 255]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_checkpoint_written_by_the_reference_classes_loads(tmp_path):
+    """A .tar written exactly as nerf/run.py:716-724 does, from the reference's own nn.Modules."""
+    sys.dont_write_bytecode = True
+    saved = sys.modules.pop("model", None)
+    sys.path.insert(0, REF)
+    try:
+        import importlib
+        refmodel = importlib.import_module("model")
+    finally:
+        sys.path.remove(REF)
+        sys.modules.pop("model", None)
+        if saved is not None:
+            sys.modules["model"] = saved
+    sd_c, sd_f = cases.weights_static()
+    nets = []
+    for sd in (sd_c, sd_f):
+        m = refmodel.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(m)
+    opt = torch.optim.Adam(params=list(nets[0].parameters()) + list(nets[1].parameters()), lr=5e-4, betas=(0.9, 0.999))
+    path = tmp_path / "200000.tar"
+    torch.save({'global_step': 200000, 'network_fn_state_dict': nets[0].state_dict(),
+                'network_fine_state_dict': nets[1].state_dict(), 'optimizer_state_dict': opt.state_dict()}, path)
+    a, b = _nets()
+    assert checkpoint.load_checkpoint(str(path), a, b) == 200000
+    for ours, sd in ((a, sd_c), (b, sd_f)):
+        got = ours.state_dict()
+        assert list(got.keys()) == list(sd.keys()) and all(np.array_equal(got[k].numpy(), sd[k]) for k in sd)
+    dn = refmodel.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27,
+                                   input_ch_time=21, use_viewdirs=True, embed_fn=None, zero_canonical=True)
+    dn.load_state_dict({k: torch.from_numpy(v) for k, v in cases.weights_dnerf().items()})
+    path = tmp_path / "800000.tar"
+    torch.save({'global_step': 800000, 'network_fn_state_dict': dn.state_dict(), 'optimizer_state_dict': {}}, path)   # run_dnerf.py:757-770
+    ours = model.DirectTemporalNeRF(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, skips=[4], use_viewdirs=True)
+    assert checkpoint.load_checkpoint(str(path), ours) == 800000
+    assert all(np.array_equal(ours.state_dict()[k].numpy(), v) for k, v in cases.weights_dnerf().items())
