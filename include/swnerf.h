@@ -107,6 +107,15 @@ int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M,
                        const float* t_emb, int L_time, int run_deform,
                        float* out /*[M,4]*/, float* dx_out /*[M,3]*/, void* stream);
 
+/* network_query_fn on bare points (nerf/load_model.py:56-74; nerf/extract_mesh.py:27-90, :155-175):
+ * pts [M,3] world positions, packed = a SWNERF_NET_CANON blob; the positional encodings are
+ * evaluated in registers.  shared_dirs == 0: dirs [M,3], one direction per point -> out [M,4] = raw
+ * [rgb(3), sigma].  shared_dirs != 0: dirs [V,3] shared by every point -> out [M,4] =
+ * [mean over the V directions of the raw rgb, sigma] (what sample_grid averages); the trunk and
+ * the density are evaluated once per point, only the view branch V times. */
+int swnerf_query_points(const float* packed, const float* pts, int64_t M, const float* dirs, int64_t n_dirs,
+                        int shared_dirs, int L_pos, int L_dir, float* out /*[M,4]*/, void* stream);
+
 /* ---- fused render pass (render_rays, nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480) -------
  * One wavefront owns one ray: sampling -> positional encoding -> MLP (MFMA, register
  * resident) -> alpha compositing -> optional hierarchical resampling, with no HBM traffic

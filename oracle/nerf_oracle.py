@@ -286,6 +286,24 @@ def render_rays_dnerf(ray_batch, sd, N_samples, N_importance=0, lindisp=False, w
     return ret
 
 
+def query_points(sd, pts, viewdirs, multires=10, multires_views=4):
+    """network_query_fn on bare points, nerf/load_model.py:56-74 (2-D inputs: pts [M,3], viewdirs [M,3])."""
+    e = torch.cat([embed(pts, multires), embed(viewdirs, multires_views)], -1)
+    return nerf_mlp(sd, e, embed_dim(multires, 3), embed_dim(multires_views, 3))
+
+
+def sample_grid_points(sd, points, viewdirs):
+    """The inner double loop of nerf/extract_mesh.py:61-79 for points [M,3] (float32) and viewdirs [V,3]:
+    per view one network query of all points; colours/densities averaged over the views in float64."""
+    cols = np.zeros((points.shape[0], viewdirs.shape[0], 3))
+    dens = np.zeros((points.shape[0], viewdirs.shape[0]))
+    for v in range(viewdirs.shape[0]):
+        out = query_points(sd, points, viewdirs[v][None].expand(points.shape[0], 3)).numpy()
+        cols[:, v] = out[:, :3]
+        dens[:, v] = out[:, 3]
+    return dens.mean(1), cols.mean(1)
+
+
 def make_ray_batch(rays_o, rays_d, near, far, frame_time=None, ndc=False, H=None, W=None, focal=None):
     """The packing done inside render(): nerf/run.py:137-158, d_nerf/run_dnerf.py:137-160.
     viewdirs are normalised BEFORE the NDC warp."""

@@ -104,12 +104,12 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     int b8[8];
     for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
 
+    int vt[9], vb[9];
+    for (int i = 0; i < 8; ++i) { vt[i] = KT_TRUNK; vb[i] = 32 * i; }
+    vt[8] = KT_DIR; vb[8] = 256;
     auto canon = [&](Packer& pk) {
         pk.trunk(params, params[20], params[21], 1, Cpos, 0);                      // ... ALPHA
         pk.seg(params[18], params[19], 256, 256, 8, 8, t8, b8);                    // FEAT
-        int vt[9], vb[9];
-        for (int i = 0; i < 8; ++i) { vt[i] = KT_TRUNK; vb[i] = 32 * i; }
-        vt[8] = KT_DIR; vb[8] = 256;
         pk.seg(params[16], params[17], 128, 256 + Cdir, 4, 9, vt, vb);             // VIEWS
         pk.seg(params[22], params[23], 3, 128, 1, 4, t8, b8);                      // RGB
     };
@@ -130,7 +130,13 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     Packer pk{st, packed, packed + SW_CANON_W_FLOATS, L_pos, L_dir, L_time, 0};
     canon(pk);
     if (pk.rc) return pk.rc;
-    if (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_FLOATS)
+    if (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_VL_OFFSET)
         return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
-    return tail(pk.w, packed);
+    if ((rc = tail(pk.w, packed))) return rc;
+    // the view branch once more, as a stream that wraps onto itself (biases: the tiles packed above)
+    Packer vl{st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time, 0};
+    vl.seg(params[16], nullptr, 128, 256 + Cdir, 4, 9, vt, vb);
+    vl.seg(params[22], nullptr, 3, 128, 1, 4, t8, b8);
+    if (vl.rc) return vl.rc;
+    return tail(vl.w, packed + SW_CANON_VL_OFFSET);
 }

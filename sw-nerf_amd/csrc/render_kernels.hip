@@ -322,6 +322,61 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
 }
 
 // ------------------------------------------------------------------------------------------
+// network_query_fn on bare points (nerf/load_model.py:56-74) with V view directions per point
+// (nerf/extract_mesh.py:27-90): trunk + density once, view branch V times.
+struct QueryDev {
+    const float* pts; int64_t M; const float* dirs; int64_t V; int shared;
+    const float* w0; const float* b0; int nbias; const float* wvl; float* out;
+};
+
+__global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
+    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_bias, P.b0, P.nbias);
+    if (tile * 32 >= P.M) return;
+    const int64_t row = tile * 32 + j;
+    const bool live = row < P.M;
+    const int64_t rr = live ? row : P.M - 1;
+    f32x16 emb[2], in[8], out[8], head;
+    pe_pos(P.pts[rr * 3], P.pts[rr * 3 + 1], P.pts[rr * 3 + 2], h, emb);
+    WStream ws;
+    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+    seg_mfma<8, 8, true>(out, in, ws);                       // feature = feature_linear(h)
+    // the ring now holds the first VIEWS steps; the views-loop region starts with the same ones
+    ws.base = reinterpret_cast<const char*>(P.wvl);
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    const int64_t nv = P.shared ? P.V : 1;
+#pragma nounroll
+    for (int64_t v = 0; v < nv; ++v) {
+        const float* dp = P.dirs + (P.shared ? v : rr) * 3;
+        f32x16 k9[9];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) k9[n] = out[n];
+        pe_dir(dp[0], dp[1], dp[2], h, k9[8]);
+        ws.bias = lds_bias + SW_CANON_BIAS_TILE_VIEWS * SW_BIAS_TILE_FLOATS + h * 16;
+        f32x16 hv[4];
+        seg_mfma<4, 9, true>(hv, k9, ws);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+        f32x16 o1[1];
+        seg_mfma<1, 4, true>(o1, hv, ws);
+        sr += o1[0][0]; sg += o1[0][1]; sb += o1[0][2];
+        ws.base = reinterpret_cast<const char*>(P.wvl);      // the region's tail is its own head
+    }
+    if (live && h == 0) {
+        const float inv = 1.f / (float)nv;
+        f32x4 r4 = {sr * inv, sg * inv, sb * inv, head[0]};
+        *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static int stream_ptrs(int kind, const float* packed, int run_deform, const float** w0, const float** b0, int* nbias, int* two) {
     *nbias = SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
     if (kind == SWNERF_NET_CANON) {
@@ -366,6 +421,22 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
     else hipLaunchKernelGGL(render_pass_kernel<false>, grid, block, lds, st, P);
     return sw_check(hipGetLastError(), "render_pass launch");
+}
+
+extern "C" int swnerf_query_points(const float* packed, const float* pts, int64_t M, const float* dirs, int64_t n_dirs,
+                                   int shared_dirs, int L_pos, int L_dir, float* out, void* stream) {
+    if (M == 0 && packed) return 0;
+    if (!packed || !pts || !dirs || !out || M < 0) return sw_fail(SWNERF_E_ARG, "query_points: NULL pointer or negative M");
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "query_points: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
+    if (shared_dirs ? n_dirs < 1 : n_dirs != M)
+        return sw_fail(SWNERF_E_ARG, "query_points: need %s directions, got %lld for %lld points", shared_dirs ? ">= 1 shared" : "one per point", (long long)n_dirs, (long long)M);
+    QueryDev P;
+    P.pts = pts; P.M = M; P.dirs = dirs; P.V = n_dirs; P.shared = shared_dirs ? 1 : 0; P.out = out;
+    P.w0 = packed; P.b0 = packed + SW_CANON_W_FLOATS; P.nbias = SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    P.wvl = packed + SW_CANON_VL_OFFSET;
+    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    hipLaunchKernelGGL(query_points_kernel, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "query_points launch");
 }
 
 extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M, int L_pos, int L_dir,

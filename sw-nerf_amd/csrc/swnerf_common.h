@@ -33,9 +33,15 @@
                          2 * SW_STEPS_TRUNK + SW_STEPS_HEAD)
 #define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 1)
 
-// blob CANON : [canon steps][ring tail = copy of first SW_RING steps][canon bias]
+// blob CANON : [canon steps][ring tail = copy of first SW_RING steps][canon bias][views loop]
+// views loop  : [VIEWS steps][RGB steps][tail = copy of the first SW_RING VIEWS steps] - the view
+//               branch as a stream that wraps onto itself, for queries of many view directions per
+//               point (swnerf_query_points: trunk and density once, view branch V times)
 #define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
-#define SW_CANON_FLOATS     (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+#define SW_CANON_VL_OFFSET  (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+#define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_STEPS_RGB + SW_RING) * SW_STEP_FLOATS)
+#define SW_CANON_FLOATS     (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
+#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 1 + 8)   // index of the first views_linears bias tile
 // blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
 // (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
 #define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)

@@ -12,7 +12,7 @@ NET_CANON, NET_DNERF = 0, 1
 
 EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs",
-           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_render_pass"]
+           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass"]
 
 
 class PassArgs(Structure):
@@ -62,6 +62,7 @@ def lib():
     L.swnerf_embed.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_mlp_forward.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                      c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_query_points.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_render_pass.argtypes = [POINTER(PassArgs), c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats"):

@@ -33,7 +33,16 @@ def batchify(fn, chunk):
 
 
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
-    """nerf/run.py:73-87."""
+    """nerf/run.py:73-87; also accepts the 2-D form of nerf/load_model.py:56-74 (inputs [N,3],
+    viewdirs [N,3] -> [N,1,4]), which goes straight to the fused point query when the encoders and
+    the network are this build's."""
+    if len(inputs.shape) == 2:
+        if (viewdirs is not None and isinstance(embed_fn, EmbedFn) and isinstance(embeddirs_fn, EmbedFn)
+                and isinstance(fn, (vallina_NeRF,)) and fn.input_ch == embed_fn.out_dim and fn.input_ch_views == embeddirs_fn.out_dim
+                and inputs.is_cuda):
+            from .mesh import query_points
+            return query_points(fn, inputs, viewdirs, shared_dirs=False)[:, None]
+        inputs = inputs[:, None]
     inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
     embedded = embed_fn(inputs_flat)
     if viewdirs is not None:

@@ -182,3 +182,8 @@ def g9_blender_frames():
         out[s] = [{"file_path": f"./{s}/r_{i}", "transform_matrix": synth.pose_spherical(float(t), -30.0 + i, 4.0).astype(float).tolist()}
                   for i, t in enumerate(thetas)]
     return out
+
+
+# ------------------------------------------------------------------ G10 mesh grid query
+G10_BOUNDS = [(-1., 1.), (-1., 2.), (-4., 2.)]          # nerf/extract_mesh.py:148
+G10_RES, G10_VIEWS = 6, 8

@@ -51,7 +51,9 @@ def test_pass_args_layout_matches_c(built, tmp_path):
 
 def test_packed_sizes_and_argument_errors_without_gpu(built):
     L = built.lib()
-    assert L.swnerf_packed_floats(0) == 610752 and L.swnerf_packed_floats(1) == 1731488 and L.swnerf_packed_floats(7) == 0
+    canon = (2368 + 8) * 256 + 78 * 32 + (144 + 16 + 8) * 256          # stream + tail, biases, views loop
+    dnerf = (1984 + 2368 + 8) * 256 + (65 + 78) * 32 + canon
+    assert L.swnerf_packed_floats(0) == canon and L.swnerf_packed_floats(1) == dnerf and L.swnerf_packed_floats(7) == 0
     # pure argument validation happens before any device call
     assert L.swnerf_render_pass(None, None) == -1 and b"NULL" in L.swnerf_last_error()
     assert L.swnerf_embed(None, 4, 3, 10, None, None) == -1

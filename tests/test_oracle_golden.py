@@ -149,3 +149,23 @@ def test_g8_dnerf_render_rays(golden):
     ref = golden("g8_dnerf_coarse_only")
     r = O.render_rays_dnerf(_rb(g, 0.25)[:128], sd, 64, 0, white_bkgd=True)
     _cmp_dict(r, ref, ["rgb_map", "disp_map", "acc_map", "z_vals", "position_delta"], atol=5e-6)
+
+
+def test_g10_mesh_grid_query(golden):
+    """nerf/extract_mesh.py sample_grid + generate_viewdirs + the 2-D network_query_fn."""
+    from swnerf import mesh
+    ref = golden("g10_mesh_query")
+    vd = mesh.generate_viewdirs(100)
+    close(vd, ref["viewdirs100"])
+    _, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
+    R = cases.G10_RES
+    ax = [np.linspace(b[0], b[1], R) for b in cases.G10_BOUNDS]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    assert np.array_equal(X, ref["X"])
+    pts = torch.tensor(np.stack([X.ravel(), Y.ravel(), Z.ravel()], -1), dtype=torch.float32)
+    dirs = torch.tensor(mesh.generate_viewdirs(cases.G10_VIEWS), dtype=torch.float32)
+    dens, col = O.sample_grid_points(sd_f, pts, dirs)
+    close(dens.reshape(R, R, R), ref["density"], atol=2e-6, rtol=1e-5)
+    close(col.reshape(R, R, R, 3), ref["color"], atol=2e-6, rtol=1e-5)
+    one = O.query_points(sd_f, pts[:40], torch.tensor(np.tile(vd[3][None], (40, 1)), dtype=torch.float32))
+    close(one, ref["per_point_raw"], atol=2e-6, rtol=1e-5)
