@@ -83,6 +83,15 @@ int swnerf_raw2outputs(const float* raw /*[N,S,4]*/, const float* z_vals /*[N,S]
                        int white_bkgd, float* rgb_map /*[N,3]*/, float* disp_map, float* acc_map,
                        float* weights /*[N,S]*/, float* depth_map, void* stream);
 
+/* Gradient of raw2outputs w.r.t. raw (autograd of ray.py:155-198; the loss of nerf/run.py:688-697
+ * reaches it through rgb_map / rgb0).  g_*: upstream gradients of the five outputs, each may be NULL;
+ * d_raw [N,S,4] is overwritten.  z_vals and rays_d get no gradient (they are detached inputs of the
+ * render path).  2 <= S <= 1024. */
+int swnerf_raw2outputs_backward(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                                int64_t N, int S, int white_bkgd, const float* g_rgb /*[N,3]*/,
+                                const float* g_disp /*[N]*/, const float* g_acc /*[N]*/, const float* g_depth /*[N]*/,
+                                const float* g_weights /*[N,S]*/, float* d_raw /*[N,S,4]*/, void* stream);
+
 /* sample_pdf (ray.py:96-153).  bins [N,nb], weights [N,nb-1]; u: NULL -> det linspace(0,1,n_samples)
  * (det=True), else [N,n_samples] uniforms (replaces torch.rand).  samples [N,n_samples].
  * If z_vals ([N,S]) and z_sorted ([N,S+n_samples]) are given, also writes

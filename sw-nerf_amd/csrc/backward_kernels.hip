@@ -1,0 +1,116 @@
+// backward_kernels.hip - gradients of the render path.
+//
+//  * raw2outputs backward: d(raw) from d(rgb_map, disp_map, acc_map, depth_map, weights)   (ray.py:155-198)
+//  * TN GEMM  dW[o][i] += sum_m A[m][o] * B[m][i]  (+ column sums for the bias gradient): the weight
+//    gradients of every Linear layer of the 8x256 MLP, v_mfma_f32_32x32x2_f32, K = rows
+// (the register-resident dX chain lives in render_kernels.hip next to the forward it mirrors)
+#include <hip/hip_runtime.h>
+#include "../../include/swnerf.h"
+#include "swnerf_common.h"
+#include "host_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// raw2outputs backward, one wave per ray.  With c = sigmoid(rgb), e = exp(-relu(sigma)*dist),
+// a = 1-e, p = 1-a+1e-10, T_i = prod_{j<i} p_j, w = a*T:
+//   G_i   = dL/dw_i = g_rgb.c_i + gA + gD*z_i + g_w_i
+//   dL/da_i = G_i*T_i - (sum_{k>i} G_k*w_k)/p_i ,   da/dsigma = dist*e*[sigma>0]
+//   dL/drgb_i = w_i * g_rgb * c_i*(1-c_i)
+// gA folds d(acc_map), the white-background term (rgb_map += 1-acc) and disp = 1/max(1e-10, D/A);
+// gD folds d(depth_map) and disp.  Prefix products and suffix sums run in double like the forward.
+#define R2B_SMAX 1024
+__global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(const float* raw, const float* zv, const float* rd, const float* noise,
+                                                              int64_t N, int S, int white, const float* g_rgb, const float* g_disp,
+                                                              const float* g_acc, const float* g_depth, const float* g_w, float* d_raw) {
+    __shared__ float sT[4][R2B_SMAX], sW[4][R2B_SMAX], sG[4][R2B_SMAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    if (ray >= N) return;
+    float* T_ = sT[wv]; float* W_ = sW[wv]; float* G_ = sG[wv];
+    const float dx = rd[ray * 3], dy = rd[ray * 3 + 1], dz = rd[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float gr = g_rgb ? g_rgb[ray * 3] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    // pass 1: forward recompute of T, w; accumulate acc and depth for the disparity term
+    double Tc = 1.0;
+    float pa = 0.f, pd = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        const float z = zv[ray * S + sc];
+        float dist = (s + 1 < S) ? (zv[ray * S + s + 1] - z) : 1e10f;
+        dist *= dnorm;
+        float sg = raw[(ray * S + sc) * 4 + 3];
+        if (noise) sg += noise[ray * S + sc];
+        float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
+        if (!live) alpha = 0.f;
+        double ps = (double)(1.f - alpha + 1e-10f);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(ps, o, 64); if (lane >= o) ps *= up; }
+        double ex = __shfl_up(ps, 1, 64);
+        if (lane == 0) ex = 1.0;
+        const float T = (float)(Tc * ex);
+        Tc *= __shfl(ps, 63, 64);
+        const float w = alpha * T;
+        if (live) { T_[s] = T; W_[s] = w; }
+        pa += w; pd += w * z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o, 64); pd += __shfl_xor(pd, o, 64); }
+    float gA = g_acc ? g_acc[ray] : 0.f, gD = g_depth ? g_depth[ray] : 0.f;
+    if (white) gA -= (gr + gg + gb);
+    if (g_disp) {
+        const float q = pd / pa;                       // disp = 1/max(1e-10, q); no gradient on the clamped / NaN branch
+        if (q > 1e-10f) { const float gq = -g_disp[ray] / (q * q); gD += gq / pa; gA -= gq * pd / (pa * pa); }
+    }
+    // pass 2: G_i, then the suffix sums of G*w from the last chunk to the first
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double carry = 0.0;
+    const int nch = (S + 63) / 64;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int s = ch * 64 + lane;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + (ray * S + sc) * 4);
+        const float z = zv[ray * S + sc];
+        const float c0 = 1.f / (1.f + expf(-r4[0])), c1 = 1.f / (1.f + expf(-r4[1])), c2 = 1.f / (1.f + expf(-r4[2]));
+        const float w = live ? W_[sc] : 0.f, T = live ? T_[sc] : 0.f;
+        float G = gr * c0 + gg * c1 + gb * c2 + gA + gD * z;
+        if (g_w) G += g_w[ray * S + sc];
+        // inclusive suffix sum of G*w over lanes >= this one, in double
+        double v = live ? (double)G * (double)w : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double dn = __shfl_down(v, o, 64); if (lane + o < 64) v += dn; }
+        double after = __shfl_down(v, 1, 64);          // sum over lanes > this one in the chunk
+        if (lane == 63) after = 0.0;
+        const double R = carry + after;
+        carry += __shfl(v, 0, 64);
+        float dist = (s + 1 < S) ? (zv[ray * S + s + 1] - z) : 1e10f;
+        dist *= dnorm;
+        float sg = r4[3];
+        if (noise) sg += noise[ray * S + sc];
+        const float e = expf(-fmaxf(sg, 0.f) * dist);
+        const float p = 1.f - (1.f - e) + 1e-10f;
+        const float dLda = G * T - (float)(R / (double)p);
+        const float dsig = (sg > 0.f) ? dLda * dist * e : 0.f;
+        if (live) {
+            f32x4 o4 = {w * gr * c0 * (1.f - c0), w * gg * c1 * (1.f - c1), w * gb * c2 * (1.f - c2), dsig};
+            *reinterpret_cast<f32x4*>(d_raw + (ray * S + s) * 4) = o4;
+        }
+    }
+}
+
+extern "C" int swnerf_raw2outputs_backward(const float* raw, const float* z_vals, const float* rays_d, const float* noise,
+                                           int64_t N, int S, int white_bkgd, const float* g_rgb, const float* g_disp,
+                                           const float* g_acc, const float* g_depth, const float* g_weights, float* d_raw,
+                                           void* stream) {
+    if (S < 2 || S > R2B_SMAX) return sw_fail(SWNERF_E_UNSUPP, "raw2outputs_backward: 2 <= S <= %d (got %d)", R2B_SMAX, S);
+    if (N == 0) return 0;
+    if (!raw || !z_vals || !rays_d || !d_raw || N < 0) return sw_fail(SWNERF_E_ARG, "raw2outputs_backward: NULL pointer / negative N");
+    hipLaunchKernelGGL(raw2outputs_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z_vals, rays_d,
+                       noise, N, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw);
+    return sw_check(hipGetLastError(), "raw2outputs_backward launch");
+}

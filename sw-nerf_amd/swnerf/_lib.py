@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libswnerf_hip.so")
 NET_CANON, NET_DNERF = 0, 1
 
 EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
-           "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs",
+           "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass"]
 
 
@@ -57,6 +57,8 @@ def lib():
                                         c_int, c_int, c_int, c_double, c_void_p, c_void_p]
     L.swnerf_raw2outputs.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_raw2outputs_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_sample_pdf.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     L.swnerf_embed.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]

@@ -101,6 +101,41 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
     return samples
 
 
+class _Raw2Outputs(torch.autograd.Function):
+    """raw2outputs with the hand-written backward kernel (gradient w.r.t. raw only: z_vals / rays_d are
+    detached inputs of the render path, nerf/run.py:398)."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, noise, white_bkgd):
+        N, S = z_vals.shape
+        dev = raw.device
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        disp = torch.empty((N,), dtype=torch.float32, device=dev)
+        acc = torch.empty((N,), dtype=torch.float32, device=dev)
+        depth = torch.empty((N,), dtype=torch.float32, device=dev)
+        w = torch.empty((N, S), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().swnerf_raw2outputs(_lib.ptr(raw), _lib.ptr(z_vals), _lib.ptr(rays_d), _lib.ptr(noise), N, S,
+                                                 int(bool(white_bkgd)), _lib.ptr(rgb), _lib.ptr(disp), _lib.ptr(acc),
+                                                 _lib.ptr(w), _lib.ptr(depth), _lib.stream_of(raw)), "raw2outputs")
+        ctx.save_for_backward(raw, z_vals, rays_d, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.white = bool(white_bkgd)
+        ctx.has_noise = noise is not None
+        return rgb, disp, acc, w, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+        raw, z_vals, rays_d, noise = ctx.saved_tensors
+        N, S = z_vals.shape
+        d_raw = torch.empty_like(raw)
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_rgb, g_disp, g_acc, g_w, g_depth = c(g_rgb), c(g_disp), c(g_acc), c(g_w), c(g_depth)
+        _lib.check(_lib.lib().swnerf_raw2outputs_backward(
+            _lib.ptr(raw), _lib.ptr(z_vals), _lib.ptr(rays_d), _lib.ptr(noise) if ctx.has_noise else None, N, S, int(ctx.white),
+            _lib.ptr(g_rgb), _lib.ptr(g_disp), _lib.ptr(g_acc), _lib.ptr(g_depth), _lib.ptr(g_w), _lib.ptr(d_raw),
+            _lib.stream_of(raw)), "raw2outputs_backward")
+        return d_raw, None, None, None, None
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None):
     """ray.py:155-198 -> (rgb_map, disp_map, acc_map, weights, depth_map).
     `noise` (extra, optional) injects the density noise instead of torch.randn * raw_noise_std."""
@@ -118,6 +153,10 @@ def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=F
             noise = torch.Tensor(np.random.rand(N, S) * raw_noise_std).to(raw.device)
     if noise is not None:
         noise = _lib.dev_f32(noise, "noise", S)
+    if raw.requires_grad and torch.is_grad_enabled():
+        if N == 0:
+            raise RuntimeError("swnerf.raw2outputs: empty batch with requires_grad")
+        return _Raw2Outputs.apply(raw, z_vals.detach(), rays_d.detach(), noise, white_bkgd)
     dev = raw.device
     rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
     disp = torch.empty((N,), dtype=torch.float32, device=dev)
