@@ -116,6 +116,25 @@ int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M,
                        const float* t_emb, int L_time, int run_deform,
                        float* out /*[M,4]*/, float* dx_out /*[M,3]*/, void* stream);
 
+/* ---- training path of the MLP (autograd of model.py:39-62) -----------------
+ * forward_train: as swnerf_mlp_forward (SWNERF_NET_CANON) and additionally saves, per row, the
+ *   activations the backward needs: act [M, swnerf_act_floats_per_row()] row-major
+ *   (h_l post-ReLU at column 256*l, l=0..7; feature_linear output at 2048; views hidden at 2304).
+ * pack_net_bwd: the transposed weight stream of the dX chain (params as for swnerf_pack_net, first 24).
+ * backward_dx: d_out [M,4] = d raw -> grad [M, same layout as act] = d(pre-activation) of every layer.
+ * gemm_tn: C[No,ldc] += A[M,lda]^T . B[M,ldb] (first No / Ni columns), bias[No] += column sums of A
+ *   (bias may be NULL): dW and db of one Linear layer from `grad` and `act`/inputs.  C and bias accumulate:
+ *   zero them first.  No <= 256. */
+size_t swnerf_packed_bwd_floats(void);
+size_t swnerf_act_floats_per_row(void);
+int swnerf_mlp_forward_train(const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
+                             float* out /*[M,4]*/, float* act, void* stream);
+int swnerf_pack_net_bwd(const float* const* params /*HOST*/, int L_pos, int L_dir, float* packed_bwd, void* stream);
+int swnerf_mlp_backward_dx(const float* packed_bwd, const float* act, const float* d_out /*[M,4]*/, int64_t M,
+                           float* grad, void* stream);
+int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
+                   float* C, int ldc, float* bias, void* stream);
+
 /* network_query_fn on bare points (nerf/load_model.py:56-74; nerf/extract_mesh.py:27-90, :155-175):
  * pts [M,3] world positions, packed = a SWNERF_NET_CANON blob; the positional encodings are
  * evaluated in registers.  shared_dirs == 0: dirs [M,3], one direction per point -> out [M,4] = raw

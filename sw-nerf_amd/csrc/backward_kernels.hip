@@ -114,3 +114,88 @@ extern "C" int swnerf_raw2outputs_backward(const float* raw, const float* z_vals
                        noise, N, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw);
     return sw_check(hipGetLastError(), "raw2outputs_backward launch");
 }
+
+// ---------------------------------------------------------------------------------------------
+// C[o][i] += sum_m A[m][o] * B[m][i]   (A [M,lda] -> No columns, B [M,ldb] -> Ni columns, C [No, ldc]),
+// bias[o] += sum_m A[m][o].   The weight gradient of one Linear layer: A = d(pre-activation), B = the
+// layer's input, K = the (ray,sample) rows.  v_mfma_f32_32x32x2_f32 with k = two rows per step:
+// lane (i, h') supplies A[m0+2s+h'][o0+i] and B[m0+2s+h'][i0+i] - both row-major operands are read
+// as two contiguous 128-B segments per wave load.  One wave owns a 32 x 256 strip of C (8 accumulators);
+// the workgroup's waves share the B rows through L1.  Row slices are split across workgroups (split-K) and
+// combined with float atomics (256 contiguous bytes per wave instruction, the full-rate shape).
+struct GemmTN { const float* A; int lda; int No; const float* B; int ldb; int Ni; float* C; int ldc; float* bias; int64_t M; int64_t rows_per_wg; };
+
+__global__ void __launch_bounds__(512, 2) gemm_tn_kernel(GemmTN P) {
+    const int lane = threadIdx.x & 63, i = lane & 31, hp = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int o0 = 32 * wv;
+    if (o0 >= P.No) return;
+    const int chunk = blockIdx.y;
+    const int i0 = 256 * chunk;
+    const int nb = min(8, (P.Ni - i0 + 31) / 32);
+    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int64_t m1 = min(P.M, m0 + P.rows_per_wg);
+    f32x16 acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const bool a_ok = (o0 + i) < P.No;
+    float bsum = 0.f;
+    const float* Ap = P.A + o0 + i;
+    const float* Bp = P.B + i0 + i;
+    for (int64_t m = m0; m < m1; m += 8) {                 // 4 k-steps (8 rows) per trip
+        float a[4], bv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = m + 2 * u + hp;
+            const bool r_ok = row < m1;
+            a[u] = (r_ok && a_ok) ? Ap[row * P.lda] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                bv[u][b] = (r_ok && b < nb && (i0 + 32 * b + i) < P.Ni) ? Bp[row * P.ldb + 32 * b] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum += a[u];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][b], acc[b], 0, 0, 0);
+        }
+    }
+    // C/D map: register r of lane (j = i, h = hp) is row o0 + frow(r,h), column i0 + 32b + j
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (b >= nb) continue;
+        const int col = i0 + 32 * b + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + sw_frow(r, hp);
+            if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
+        }
+    }
+    if (P.bias && chunk == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (hp == 0 && a_ok) atomicAdd(P.bias + o0 + i, bsum);
+    }
+}
+
+extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
+                              float* C, int ldc, float* bias, void* stream) {
+    if (M == 0) return 0;
+    if (!A || !B || !C || M < 0 || No < 1 || No > 256 || Ni < 1 || lda < No || ldb < Ni || ldc < Ni)
+        return sw_fail(SWNERF_E_ARG, "gemm_tn: bad arguments (M=%lld No=%d Ni=%d lda=%d ldb=%d ldc=%d)", (long long)M, No, Ni, lda, ldb, ldc);
+    GemmTN P;
+    P.A = A; P.lda = lda; P.No = No; P.B = B; P.ldb = ldb; P.Ni = Ni; P.C = C; P.ldc = ldc; P.bias = bias; P.M = M;
+    // split the rows over ~2 workgroups per CU, at least 512 rows each (multiple of 8)
+    int64_t nwg = (M + 511) / 512;
+    if (nwg > 512) nwg = 512;
+    int64_t rows = (M + nwg - 1) / nwg;
+    rows = (rows + 7) / 8 * 8;
+    P.rows_per_wg = rows;
+    nwg = (M + rows - 1) / rows;
+    const int nstrips = (No + 31) / 32;
+    const dim3 grid((unsigned)nwg, (unsigned)((Ni + 255) / 256)), block(64 * nstrips);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "gemm_tn launch");
+}

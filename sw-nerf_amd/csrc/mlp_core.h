@@ -122,25 +122,67 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
 }
 
 // out[n] (+)= sum_kt  Wtile(n,kt) . kin[kt]       NT output tiles, KT input tiles.
-// INIT: accumulators start from the bias (so no separate bias pass); else accumulate.
-template <int NT, int KT, bool INIT>
-__device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws) {
+// INIT: how the accumulators start -
+//   SEG_ACC (false) keep accumulating | SEG_BIAS (true) the bias tile (so no separate bias pass) |
+//   SEG_ZERO zeros | SEG_BIAS_SCALED the bias tile times a per-lane scalar (backward: w_alpha * d sigma)
+enum { SEG_ACC = 0, SEG_BIAS = 1, SEG_ZERO = 2, SEG_BIAS_SCALED = 3 };
+template <int NT, int KT, int INIT>
+__device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, float scale = 1.f) {
     constexpr int NS = NT * KT * 4;
     static_assert(NS % SW_RING == 0, "segment must keep the ring phase");
-    if (INIT) {
+    if (INIT == SEG_BIAS || INIT == SEG_BIAS_SCALED) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(ws.bias + n * SW_BIAS_TILE_FLOATS + 4 * g);
-                out[n][4 * g + 0] = b[0]; out[n][4 * g + 1] = b[1];
-                out[n][4 * g + 2] = b[2]; out[n][4 * g + 3] = b[3];
+                if (INIT == SEG_BIAS_SCALED) {
+                    out[n][4 * g + 0] = b[0] * scale; out[n][4 * g + 1] = b[1] * scale;
+                    out[n][4 * g + 2] = b[2] * scale; out[n][4 * g + 3] = b[3] * scale;
+                } else {
+                    out[n][4 * g + 0] = b[0]; out[n][4 * g + 1] = b[1];
+                    out[n][4 * g + 2] = b[2]; out[n][4 * g + 3] = b[3];
+                }
             }
         }
         ws.bias += NT * SW_BIAS_TILE_FLOATS;
+    } else if (INIT == SEG_ZERO) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[n][r] = 0.f;
     }
     seg_steps<0, NS, NT, KT>(out, kin, ws);
     ws.base += NS * 1024;
+}
+
+// ---- activation tiles <-> row-major [M, ld] buffers (training path) ------------------------------
+// register r = 4g+e of lane (j,h) of tile n is feature 32n + 8g + 4h + e of row j: 16 contiguous bytes
+template <int NT>
+__device__ __forceinline__ void tiles_store(float* base, int64_t row, int ld, bool live, int h, const f32x16 (&t)[NT]) {
+    if (!live) return;
+    float* p = base + row * ld + 4 * h;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {t[n][4 * g], t[n][4 * g + 1], t[n][4 * g + 2], t[n][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(p + 32 * n + 8 * g) = v;
+        }
+}
+
+// t[n][r] = (act[row][32n + feature(r,h)] > 0) ? t[n][r] : 0     (ReLU backward mask from the stored activation)
+template <int NT>
+__device__ __forceinline__ void tiles_mask(const float* base, int64_t row, int ld, int h, f32x16 (&t)[NT]) {
+    const float* p = base + row * ld + 4 * h;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + 32 * n + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[n][4 * g + e] = (a[e] > 0.f) ? t[n][4 * g + e] : 0.f;
+        }
 }
 
 // cooperative copy of a bias stream into LDS (whole block; ends with a barrier)
@@ -199,9 +241,11 @@ __device__ __forceinline__ void pe_time(float t, int h, f32x16& e) {
 // deform_pass: layer 0 also takes the time-embedding k-tile (model.py:129: cat[new_pts, t]).
 // Returns with `in` = relu(layer-7 output) and `head` = the 1-tile head applied to it
 // (alpha_linear for the canonical net, _time_out for the deformation net).
-template <bool DNERF>
+// TRAIN: also stores every layer's post-ReLU activation to act[arow][256*l ...] (row-major, ld SW_ACT_LD).
+template <bool DNERF, bool TRAIN = false>
 __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool deform_pass, int h,
-                                           f32x16 (&in)[8], f32x16 (&out)[8], f32x16& head, WStream& ws) {
+                                           f32x16 (&in)[8], f32x16 (&out)[8], f32x16& head, WStream& ws,
+                                           float* act = nullptr, int64_t arow = 0, bool alive = false) {
 #pragma nounroll
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
@@ -209,21 +253,22 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool
                 f32x16 k3[3];
                 k3[0] = emb[0]; k3[1] = emb[1];
                 pe_time(t, h, k3[2]);
-                seg_mfma<8, 3, true>(out, k3, ws);
+                seg_mfma<8, 3, SEG_BIAS>(out, k3, ws);
             } else {
-                seg_mfma<8, 2, true>(out, emb, ws);
+                seg_mfma<8, 2, SEG_BIAS>(out, emb, ws);
             }
         } else {
-            seg_mfma<8, 8, true>(out, in, ws);
-            if (l == 5) seg_mfma<8, 2, false>(out, emb, ws);   // skip: cat[input_pts, h] (model.py:45-46)
+            seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
+            if (l == 5) seg_mfma<8, 2, SEG_ACC>(out, emb, ws);   // skip: cat[input_pts, h] (model.py:45-46)
         }
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) in[n][r] = fmaxf(out[n][r], 0.f);
+        if (TRAIN) tiles_store<8>(act + 256 * l, arow, SW_ACT_LD, alive, h, in);   // h_l, post-ReLU
     }
     f32x16 hd[1];
-    seg_mfma<1, 8, true>(hd, in, ws);
+    seg_mfma<1, 8, SEG_BIAS>(hd, in, ws);
     head = hd[0];
 }
 
@@ -231,18 +276,18 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool
 // `in` = relu(layer 7).  On return rgb[0..2] of lane half 0 = raw rgb of row j (model.py:49-58).
 __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[8], float d0, float d1, float d2,
                                            int h, f32x16& rgb, WStream& ws) {
-    seg_mfma<8, 8, true>(out, in, ws);                      // feature = feature_linear(h)
+    seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                  // feature = feature_linear(h)
     f32x16 k9[9];
 #pragma unroll
     for (int n = 0; n < 8; ++n) k9[n] = out[n];
     pe_dir(d0, d1, d2, h, k9[8]);                           // cat[feature, input_views]
     f32x16 hv[4];
-    seg_mfma<4, 9, true>(hv, k9, ws);
+    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
     f32x16 o[1];
-    seg_mfma<1, 4, true>(o, hv, ws);
+    seg_mfma<1, 4, SEG_BIAS>(o, hv, ws);
     rgb = o[0];
 }

@@ -24,6 +24,9 @@ struct PackSeg {
     int ktype[10], kbase[10];
     int Lp, Ld, Lt;
     float* dstW; float* dstB;
+    // transpose != 0 (backward stream): the GEMM's output rows are W's COLUMNS row0.. (out_dim of them) and
+    // its k index runs over W's ROWS (kvalid of them): value = W[kbase + col][row0 + row]
+    int transpose, row0, kvalid;
 };
 
 __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
@@ -44,7 +47,12 @@ __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
             case KT_TIME: col = sw_time_col(r, h, s.Lt); break;
         }
         float v = 0.f;
-        if (row < s.out_dim && col >= 0) v = s.W[(size_t)row * s.in_dim + s.kbase[kt] + col];
+        if (!s.transpose) {
+            if (row < s.out_dim && col >= 0) v = s.W[(size_t)row * s.in_dim + s.kbase[kt] + col];
+        } else {
+            const int k = s.kbase[kt] + col;
+            if (row < s.out_dim && k < s.kvalid) v = s.W[(size_t)k * s.in_dim + s.row0 + row];
+        }
         s.dstW[e] = v;
     }
     if (s.b && e < s.NT * SW_BIAS_TILE_FLOATS) {
@@ -63,11 +71,25 @@ struct Packer {
         s.W = W; s.b = bias; s.out_dim = out_dim; s.in_dim = in_dim; s.NT = NT; s.KT = KT;
         for (int i = 0; i < 10; ++i) { s.ktype[i] = i < KT ? kt[i] : 0; s.kbase[i] = i < KT ? kb[i] : 0; }
         s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
+        s.transpose = 0; s.row0 = 0; s.kvalid = 0;
+        launch(s, NT, KT, bias != nullptr);
+    }
+    // transposed segment of the backward stream: out rows = W columns [row0, row0+n_out), k = W rows [0, kvalid)
+    void segT(const float* W, int w_rows, int w_cols, int row0, int n_out, int NT, int KT) {
+        if (rc) return;
+        PackSeg s;
+        s.W = W; s.b = nullptr; s.out_dim = n_out; s.in_dim = w_cols; s.NT = NT; s.KT = KT;
+        for (int i = 0; i < 10; ++i) { s.ktype[i] = KT_TRUNK; s.kbase[i] = 32 * i; }
+        s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
+        s.transpose = 1; s.row0 = row0; s.kvalid = w_rows;
+        launch(s, NT, KT, false);
+    }
+    void launch(PackSeg& s, int NT, int KT, bool has_bias) {
         const int total = NT * KT * 4 * SW_STEP_FLOATS;
         hipLaunchKernelGGL(pack_seg_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s);
         rc = sw_check(hipGetLastError(), "pack_net launch");
         w += total;
-        if (bias) b += NT * SW_BIAS_TILE_FLOATS;
+        if (has_bias) b += NT * SW_BIAS_TILE_FLOATS;
     }
     // one 8-layer trunk + 1-tile head; P = {W0,b0,...,W7,b7}, head = {Wh,bh}
     void trunk(const float* const* P, const float* Wh, const float* bh, int head_out, int Cpos, int Ctime) {
@@ -139,4 +161,31 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     vl.seg(params[22], nullptr, 3, 128, 1, 4, t8, b8);
     if (vl.rc) return vl.rc;
     return tail(vl.w, packed + SW_CANON_VL_OFFSET);
+}
+
+// The backward (dX chain) stream of a canonical net: transposed weights in the order
+// mlp_backward_dx_kernel consumes them (swnerf_common.h SW_BWD_*), then alpha_linear.weight as 8 bias tiles.
+extern "C" int swnerf_pack_net_bwd(const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
+    if (!params || !packed_bwd) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: NULL pointer");
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "pack_net_bwd: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
+    for (int i = 0; i < 24; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: params[%d] is NULL", i);
+    const int Cpos = 3 * (1 + 2 * L_pos), Cdir = 3 * (1 + 2 * L_dir);
+    hipStream_t st = (hipStream_t)stream;
+    Packer pk{st, packed_bwd, packed_bwd + SW_BWD_W_FLOATS, L_pos, L_dir, 0, 0};
+    pk.segT(params[22], 3, 128, 0, 128, 4, 1);                       // rgb_linear.weight [3,128]^T
+    pk.segT(params[16], 128, 256 + Cdir, 0, 256, 8, 4);              // views_linears.0.weight[:, :256]^T
+    pk.segT(params[18], 256, 256, 0, 256, 8, 8);                     // feature_linear.weight^T
+    for (int l = 7; l >= 1; --l)                                      // pts_linears.l.weight[:, -256:]^T
+        pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
+    if (pk.rc) return pk.rc;
+    if (pk.w != packed_bwd + (size_t)SW_BWD_STEPS * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: internal layout mismatch");
+    int rc = sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
+    if (rc) return rc;
+    // alpha_linear.weight [1,256] laid out like a bias vector: tile n, [h][r] = w[32n + frow(r,h)]
+    PackSeg s;
+    s.W = params[20]; s.b = params[20]; s.out_dim = 256; s.in_dim = 256; s.NT = 8; s.KT = 0;
+    for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
+    s.Lp = s.Ld = s.Lt = 0; s.dstW = packed_bwd; s.dstB = packed_bwd + SW_BWD_W_FLOATS; s.transpose = 0; s.row0 = 0; s.kvalid = 0;
+    hipLaunchKernelGGL(pack_seg_kernel, dim3(1), dim3(256), 0, st, s);
+    return sw_check(hipGetLastError(), "pack_net_bwd launch");
 }

@@ -258,9 +258,10 @@ struct MlpDev {
     const float* t_emb; int Ct;
     const float* w0; const float* b0; int nbias; int two_pass;
     float* out; float* dx;
+    float* act;             // TRAIN: [M, SW_ACT_LD] activations saved for the backward pass
 };
 
-template <bool DNERF>
+template <bool DNERF, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,11 +294,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
             }
         }
     } else {
-        trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+        trunk_pass<false, TRAIN>(emb, 0.f, false, h, in, out, head, ws, P.act, row, live);
     }
     // view-direction features: gathered like the position ones
     f32x16 k9[9];
-    seg_mfma<8, 8, true>(out, in, ws);
+    seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
+    if (TRAIN) tiles_store<8>(P.act + SW_ACT_FEAT, row, SW_ACT_LD, live, h, out);
 #pragma unroll
     for (int n = 0; n < 8; ++n) k9[n] = out[n];
 #pragma unroll
@@ -306,13 +308,14 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
         k9[8][a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
     }
     f32x16 hv[4];
-    seg_mfma<4, 9, true>(hv, k9, ws);
+    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+    if (TRAIN) tiles_store<4>(P.act + SW_ACT_HV, row, SW_ACT_LD, live, h, hv);
     f32x16 o1[1];
-    seg_mfma<1, 4, true>(o1, hv, ws);
+    seg_mfma<1, 4, SEG_BIAS>(o1, hv, ws);
     rgb = o1[0];
     if (live && h == 0) {
         f32x4 r4 = {rgb[0], rgb[1], rgb[2], head[0]};
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
     WStream ws;
     ws_start(ws, P.w0, lds_bias, lds_ring, lane);
     trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
-    seg_mfma<8, 8, true>(out, in, ws);                       // feature = feature_linear(h)
+    seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                   // feature = feature_linear(h)
     // the ring now holds the first VIEWS steps; the views-loop region starts with the same ones
     ws.base = reinterpret_cast<const char*>(P.wvl);
     float sr = 0.f, sg = 0.f, sb = 0.f;
@@ -359,13 +362,13 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
         pe_dir(dp[0], dp[1], dp[2], h, k9[8]);
         ws.bias = lds_bias + SW_CANON_BIAS_TILE_VIEWS * SW_BIAS_TILE_FLOATS + h * 16;
         f32x16 hv[4];
-        seg_mfma<4, 9, true>(hv, k9, ws);
+        seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
         f32x16 o1[1];
-        seg_mfma<1, 4, true>(o1, hv, ws);
+        seg_mfma<1, 4, SEG_BIAS>(o1, hv, ws);
         sr += o1[0][0]; sg += o1[0][1]; sb += o1[0][2];
         ws.base = reinterpret_cast<const char*>(P.wvl);      // the region's tail is its own head
     }
@@ -374,6 +377,77 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
         f32x4 r4 = {sr * inv, sg * inv, sb * inv, head[0]};
         *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of the MLP w.r.t. its activations (the "dX chain"), one wave per 32 rows, mirroring the
+// forward: transposed weight streams, the same register-resident accumulator->operand hand-over, the
+// ReLU derivative taken from the saved activations.  Writes d(pre-activation) of every layer to
+// grad[M, SW_ACT_LD] (same column map as act) for the weight-gradient GEMMs.   model.py:39-62 reversed.
+struct DxDev {
+    const float* w0; const float* b0;      // backward stream; its 8 "bias" tiles = alpha_linear.weight
+    const float* act; const float* d_out;  // [M, SW_ACT_LD], [M,4]
+    int64_t M; float* grad;
+};
+
+__global__ void __launch_bounds__(256, 1) mlp_backward_dx_kernel(DxDev P) {
+    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_bias, P.b0, SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS);
+    if (tile * 32 >= P.M) return;
+    const int64_t row = tile * 32 + j;
+    const bool live = row < P.M;
+    const int64_t rr = live ? row : P.M - 1;
+    const f32x4 dr = *reinterpret_cast<const f32x4*>(P.d_out + rr * 4);     // d rgb(3), d sigma
+    WStream ws;
+    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    // d hv = rgb_linear.weight^T . d rgb, masked by hv > 0           (4 tiles <- 1 k-tile holding 3 channels)
+    f32x16 k1[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) k1[0][r] = 0.f;
+    k1[0][0] = h ? 0.f : dr[0]; k1[0][1] = h ? 0.f : dr[1]; k1[0][2] = h ? 0.f : dr[2];
+    f32x16 dhv[4];
+    seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
+    tiles_mask<4>(P.act + SW_ACT_HV, rr, SW_ACT_LD, h, dhv);
+    tiles_store<4>(P.grad + SW_ACT_HV, row, SW_ACT_LD, live, h, dhv);
+    // d feature = views_linears.0.weight[:, :256]^T . d hv            (no activation on feature_linear)
+    f32x16 in[8], out[8];
+    seg_mfma<8, 4, SEG_ZERO>(in, dhv, ws);
+    tiles_store<8>(P.grad + SW_ACT_FEAT, row, SW_ACT_LD, live, h, in);
+    // d h7 = feature_linear.weight^T . d feature + alpha_linear.weight * d sigma, masked by h7 > 0
+    seg_mfma<8, 8, SEG_BIAS_SCALED>(out, in, ws, dr[3]);
+#pragma nounroll
+    for (int l = 7; l >= 1; --l) {
+        // out = d h_l;  d pre_l = out . [h_l > 0];  d h_{l-1} = W_l[:, -256:]^T . d pre_l
+#pragma unroll
+        for (int n = 0; n < 8; ++n) in[n] = out[n];
+        tiles_mask<8>(P.act + 256 * l, rr, SW_ACT_LD, h, in);
+        tiles_store<8>(P.grad + 256 * l, row, SW_ACT_LD, live, h, in);
+        seg_mfma<8, 8, SEG_ZERO>(out, in, ws);
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) in[n] = out[n];
+    tiles_mask<8>(P.act, rr, SW_ACT_LD, h, in);                          // d pre_0 (the inputs get no gradient)
+    tiles_store<8>(P.grad, row, SW_ACT_LD, live, h, in);
+}
+
+extern "C" size_t swnerf_packed_bwd_floats(void) { return (size_t)SW_BWD_FLOATS; }
+extern "C" size_t swnerf_act_floats_per_row(void) { return (size_t)SW_ACT_LD; }
+
+extern "C" int swnerf_mlp_forward_train(const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
+                                        float* out, float* act, void* stream);
+extern "C" int swnerf_mlp_backward_dx(const float* packed_bwd, const float* act, const float* d_out, int64_t M,
+                                      float* grad, void* stream) {
+    if (M == 0 && packed_bwd) return 0;
+    if (!packed_bwd || !act || !d_out || !grad || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_backward_dx: NULL pointer or negative M");
+    DxDev P;
+    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_BWD_W_FLOATS; P.act = act; P.d_out = d_out; P.M = M; P.grad = grad;
+    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    hipLaunchKernelGGL(mlp_backward_dx_kernel, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "mlp_backward_dx launch");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -450,7 +524,7 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     P.x = x; P.M = M; P.Lp = L_pos; P.Ld = L_dir; P.Lt = L_time;
     P.Cpos = 3 * (1 + 2 * L_pos); P.C = P.Cpos + 3 * (1 + 2 * L_dir);
     P.t_emb = t_emb; P.Ct = 1 + 2 * L_time;
-    P.out = out; P.dx = dx_out;
+    P.out = out; P.dx = dx_out; P.act = nullptr;
     int rc = stream_ptrs(kind, packed, run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -459,4 +533,20 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     if (kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(mlp_forward_kernel<true>, grid, block, lds, st, P);
     else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, lds, st, P);
     return sw_check(hipGetLastError(), "mlp_forward launch");
+}
+
+extern "C" int swnerf_mlp_forward_train(const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
+                                        float* out, float* act, void* stream) {
+    if (M == 0 && packed) return 0;
+    if (!packed || !x || !out || !act || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_forward_train: NULL pointer or negative M");
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "mlp_forward_train: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
+    MlpDev P;
+    P.x = x; P.M = M; P.Lp = L_pos; P.Ld = L_dir; P.Lt = 0;
+    P.Cpos = 3 * (1 + 2 * L_pos); P.C = P.Cpos + 3 * (1 + 2 * L_dir);
+    P.t_emb = nullptr; P.Ct = 1; P.out = out; P.dx = nullptr; P.act = act;
+    int rc = stream_ptrs(SWNERF_NET_CANON, packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "mlp_forward_train launch");
 }

@@ -48,6 +48,18 @@
 #define SW_DNERF_A_FLOATS   (SW_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
 #define SW_DNERF_FLOATS     (SW_DNERF_A_FLOATS + SW_CANON_FLOATS)
 
+// ---- training path: per-row activation / gradient buffers [M, SW_ACT_LD], row-major -----------------
+// columns: h_l (post-ReLU) at 256*l for l = 0..7 | feature_linear output at 2048 | views hidden (post-ReLU) at 2304
+#define SW_ACT_LD    2432
+#define SW_ACT_FEAT  2048
+#define SW_ACT_HV    2304
+// backward weight stream (transposed weights, execution order of the dX chain):
+// RGB^T (4x1) | VIEWS^T (8x4) | FEAT^T (8x8) | L7^T .. L1^T (8x8 each); then the alpha_linear weight as 8 bias tiles
+#define SW_BWD_STEPS (16 + 128 + 256 + 7 * 256)
+#define SW_BWD_W_FLOATS ((SW_BWD_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_BWD_BIAS_TILES 8
+#define SW_BWD_FLOATS (SW_BWD_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+
 // C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile
 SW_HD int sw_frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -12,7 +12,9 @@ NET_CANON, NET_DNERF = 0, 1
 
 EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
-           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass"]
+           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
+           "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
+           "swnerf_mlp_backward_dx", "swnerf_gemm_tn"]
 
 
 class PassArgs(Structure):
@@ -66,8 +68,16 @@ def lib():
                                      c_int, c_void_p, c_void_p, c_void_p]
     L.swnerf_query_points.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_render_pass.argtypes = [POINTER(PassArgs), c_void_p]
+    L.swnerf_packed_bwd_floats.restype = c_size_t
+    L.swnerf_packed_bwd_floats.argtypes = []
+    L.swnerf_act_floats_per_row.restype = c_size_t
+    L.swnerf_act_floats_per_row.argtypes = []
+    L.swnerf_mlp_forward_train.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_pack_net_bwd.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_mlp_backward_dx.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    L.swnerf_gemm_tn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
-        if name not in ("swnerf_last_error", "swnerf_packed_floats"):
+        if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row"):
             getattr(L, name).restype = c_int
     if L.swnerf_version() != 100:
         raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 100")

@@ -45,6 +45,60 @@ class _NoBackward(torch.autograd.Function):
             "run the render path under torch.no_grad()")
 
 
+class _MlpTrain(torch.autograd.Function):
+    """Differentiable forward of the static 8x256 net: the forward kernel saves
+    every layer's activation; backward = the register-resident dX chain over the transposed weight
+    stream + one TN MFMA GEMM per Linear layer for dW / db.  Inputs (embedded points) get no gradient,
+    like in the reference's training loop (rays are data)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        kind, packed, Lp, Ld, _ = module.packed()
+        L = _lib.lib()
+        M = x.shape[0]
+        out = torch.empty((M, 4), dtype=torch.float32, device=x.device)
+        act = torch.empty((M, L.swnerf_act_floats_per_row()), dtype=torch.float32, device=x.device)
+        _lib.check(L.swnerf_mlp_forward_train(_lib.ptr(packed), _lib.ptr(x), M, Lp, Ld, _lib.ptr(out), _lib.ptr(act),
+                                              _lib.stream_of(x)), "mlp_forward_train")
+        ctx.module, ctx.bands = module, (Lp, Ld)
+        ctx.save_for_backward(x, act, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("swnerf: gradients w.r.t. the embedded inputs are not built (rays are data in train())")
+        x, act, *params = ctx.saved_tensors
+        module = ctx.module
+        L = _lib.lib()
+        M = x.shape[0]
+        d_out = d_out.contiguous().float()
+        grad = torch.empty_like(act)
+        st = _lib.stream_of(x)
+        _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(act), _lib.ptr(d_out), M, _lib.ptr(grad), st),
+                   "mlp_backward_dx")
+        g = [torch.zeros_like(p, dtype=torch.float32) for p in params]      # order: _CANON_ORDER
+        Cpos, Cdir = module.input_ch, module.input_ch_views
+
+        def gemm(A, a_col, No, B, b_col, Ni, wi, c_col, with_bias):
+            C = g[wi]
+            _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
+                                        C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(g[wi + 1]) if with_bias else None, st),
+                       "gemm_tn")
+
+        gemm(grad, 0, 256, x, 0, Cpos, 0, 0, True)                                   # pts_linears.0
+        for l in (1, 2, 3, 4, 6, 7):
+            gemm(grad, 256 * l, 256, act, 256 * (l - 1), 256, 2 * l, 0, True)
+        gemm(grad, 1280, 256, x, 0, Cpos, 10, 0, True)                               # pts_linears.5 = [pts | h4]
+        gemm(grad, 1280, 256, act, 1024, 256, 10, Cpos, False)
+        gemm(grad, 2304, 128, act, 2048, 256, 16, 0, True)                           # views_linears.0 = [feature | dirs]
+        gemm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
+        gemm(grad, 2048, 256, act, 1792, 256, 18, 0, True)                           # feature_linear
+        gemm(d_out, 3, 1, act, 1792, 256, 20, 0, True)                               # alpha_linear
+        gemm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
+        return (None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
+
+
 def _tag_no_backward(out, module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         return _NoBackward.apply(out, *list(module.parameters()))
@@ -58,6 +112,38 @@ class _PackedMixin:
     def _init_pack(self):
         self._pack_key = None
         self._packed = None
+        self._pack_bwd_key = None
+        self._packed_bwd = None
+
+    def packed_bwd(self):
+        """The transposed weight stream of the backward dX chain (static nets), cached like packed()."""
+        kind, names, Lp, Ld, Lt = self._pack_params()
+        sd = dict(self.named_parameters())
+        ps = [sd[n] for n in names[:24]]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._pack_bwd_key:
+            L = _lib.lib()
+            ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
+            arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_bwd_floats(), dtype=torch.float32, device=ps[0].device)
+            _lib.check(L.swnerf_pack_net_bwd(arr, Lp, Ld, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_bwd")
+            self._packed_bwd, self._pack_bwd_key = buf, key
+        return self._packed_bwd
+
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _forward_train(self, x):
+        """Differentiable forward (static nets)."""
+        kind, names, Lp, Ld, Lt = self._pack_params()
+        x = _lib.dev_f32(x, "x", self.input_ch + self.input_ch_views)
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, x.shape[-1])
+        if flat.shape[0] == 0:
+            return torch.empty((*lead, 4), dtype=torch.float32, device=x.device)
+        sd = dict(self.named_parameters())
+        out = _MlpTrain.apply(self, flat, *[sd[n] for n in names[:24]])
+        return out.reshape(*lead, 4)
 
     def _check_arch(self):
         if not (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.use_viewdirs):
@@ -136,6 +222,8 @@ class vallina_NeRF(nn.Module, _PackedMixin):
         return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
 
     def forward(self, x):
+        if self._wants_grad():
+            return self._forward_train(x)
         return self._forward_hip(x)[0]
 
 
@@ -160,7 +248,7 @@ class NeRFOriginal(nn.Module, _PackedMixin):
         return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
 
     def forward(self, x, ts):
-        out, _ = self._forward_hip(x)
+        out = self._forward_train(x) if self._wants_grad() else self._forward_hip(x)[0]
         return out, torch.zeros_like(x[..., :3])
 
 

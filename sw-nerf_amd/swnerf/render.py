@@ -70,6 +70,8 @@ def closure_embedders(network_query_fn):
 def fused_plan(network_query_fn, nets, need_time=False):
     """Returns (L_pos, L_dir, L_time) when every net is a swnerf module on the GPU and the
     closure's encoders are the standard ones matching the nets' input sizes; else None."""
+    if torch.is_grad_enabled() and any(p.requires_grad for net in nets if isinstance(net, torch.nn.Module) for p in net.parameters()):
+        return None          # training: the differentiable op path (the fused pass has no backward yet)
     emb = closure_embedders(network_query_fn)
     ef, edf, etf = emb.get("embed_fn"), emb.get("embeddirs_fn"), emb.get("embedtime_fn")
     if not (isinstance(ef, EmbedFn) and isinstance(edf, EmbedFn) and ef.input_dims == 3 and edf.input_dims == 3):

@@ -58,3 +58,89 @@ def test_raw2outputs_backward(dev, S, white, use_noise):
     r_gpu.grad = None
     ray.raw2outputs(r_gpu, T(z).to(dev), T(d).to(dev), 0, white)[0].pow(2).sum().backward()
     relclose(r_gpu.grad, r_cpu.grad, rtol=2e-4, atol=2e-6, what="d raw from rgb only")
+
+
+def _static_net(dev, sd_np):
+    import swnerf.model as model
+    m = model.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    m.load_state_dict({k: T(v) for k, v in sd_np.items()})
+    return m.to(dev)
+
+
+def _grad_check(ours, ref, what, rtol=2e-4):
+    """per tensor: max |delta| <= rtol * max |ref grad| (gradients are sums over rows of fp32 products)"""
+    for name, g in ours.items():
+        r = ref[name].double().numpy()
+        d = np.abs(g.detach().cpu().double().numpy() - r).max()
+        scale = max(np.abs(r).max(), 1e-12)
+        assert d <= rtol * scale, f"{what} {name}: max err {d:.3e} vs max |grad| {scale:.3e} (ratio {d/scale:.2e})"
+
+
+@pytest.mark.parametrize("M", [300, 32, 1])
+def test_mlp_backward_matches_autograd(dev, M):
+    sd_np, _ = cases.weights_static()
+    g = cases.g4_inputs()
+    x = T(g["x"][:M])
+    G = T(np.random.default_rng(9).standard_normal((M, 4)).astype(np.float32))
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
+    (O.nerf_mlp(sd, x) * G).sum().backward()
+    net = _static_net(dev, sd_np)
+    out = net(x.to(dev))
+    assert out.requires_grad and out.shape == (M, 4)
+    (out * G.to(dev)).sum().backward()
+    _grad_check({k: p.grad for k, p in net.named_parameters()}, {k: v.grad for k, v in sd.items()}, f"M={M}")
+    # a second backward accumulates (what an optimizer loop without zero_grad would see)
+    (net(x.to(dev)) * G.to(dev)).sum().backward()
+    _grad_check({k: p.grad / 2 for k, p in net.named_parameters()}, {k: v.grad for k, v in sd.items()}, "accumulated")
+
+
+def test_training_step_matches_autograd(dev):
+    """One step of the reference's training loss (nerf/run.py:688-697) on the differentiable op path:
+    coarse-only and coarse+fine, gradients of every parameter vs autograd through the CPU oracle."""
+    import swnerf.embedder as embedder, swnerf.render as render
+    sd_c, sd_f = cases.weights_static()
+    g = cases.g7_inputs(n=48, seed=77)
+    rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.)
+    target = T(np.random.default_rng(3).uniform(0, 1, (48, 3)).astype(np.float32))
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = embedder.get_embedder(4, 3, 0)
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, netchunk=1024)   # several chunks
+    img2mse = lambda x, y: torch.mean((x - y) ** 2)
+    # ---- coarse only
+    oc = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_c).items()}
+    r = O.render_rays(rb, oc, None, 64, 0, white_bkgd=True)
+    img2mse(r["rgb_map"], target).backward()
+    net_c = _static_net(dev, sd_c)
+    ret = render.render_rays(rb.to(dev), net_c, q, 64, N_importance=0, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    loss = img2mse(ret["rgb_map"], target.to(dev))
+    loss.backward()
+    _grad_check({k: p.grad for k, p in net_c.named_parameters()}, {k: v.grad for k, v in oc.items()}, "coarse-only step", rtol=5e-4)
+    # ---- coarse + fine, both losses; the resampled depths are detached (nerf/run.py:398) - feed the oracle OUR z_fine
+    # so that the comparison is not about sample_pdf's conditioning
+    net_c.zero_grad()
+    net_f = _static_net(dev, sd_f)
+    ret = render.render_rays(rb.to(dev), net_c, q, 64, N_importance=128, network_fine=net_f, white_bkgd=True)
+    loss = img2mse(ret["rgb_map"], target.to(dev)) + img2mse(ret["rgb0"], target.to(dev))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in list(net_c.parameters()) + list(net_f.parameters()))
+    # fine net alone on fixed depths: gradient parity
+    with torch.no_grad():
+        z_fine = render.render_pass(rb.to(dev), net_c, 64, white_bkgd=True, want=[], n_importance=128)["z_fine"].cpu()
+    of = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_f).items()}
+    pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z_fine[..., None]
+    raw = O.run_network(of, pts, rb[:, -3:])
+    img2mse(O.raw2outputs(raw, z_fine, rb[:, 3:6], 0., True)[0], target).backward()
+    net_f.zero_grad()
+    import swnerf.ray as ray
+    raw_g = q(pts.to(dev), rb[:, -3:].to(dev), net_f)
+    img2mse(ray.raw2outputs(raw_g, z_fine.to(dev), rb[:, 3:6].to(dev), 0, True)[0], target.to(dev)).backward()
+    _grad_check({k: p.grad for k, p in net_f.named_parameters()}, {k: v.grad for k, v in of.items()}, "fine net, fixed depths", rtol=5e-4)
+    # an Adam step on these gradients changes the render (weights are re-packed automatically)
+    opt = torch.optim.Adam(list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    with torch.no_grad():
+        before = q(pts.to(dev)[:4], rb[:4, -3:].to(dev), net_f).clone()
+    opt.step()
+    with torch.no_grad():
+        after = q(pts.to(dev)[:4], rb[:4, -3:].to(dev), net_f)
+    assert float((after - before).abs().max()) > 1e-5
