@@ -11,6 +11,12 @@ pytestmark = pytest.mark.gpu
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 
 
+@pytest.fixture(autouse=True)
+def _grad():
+    with torch.enable_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()

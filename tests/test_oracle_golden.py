@@ -12,7 +12,12 @@ import cases
 from oracle import nerf_oracle as O
 
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 
 
 def close(a, b, atol=0.0, rtol=0.0):
