@@ -125,13 +125,20 @@ extern "C" int swnerf_raw2outputs_backward(const float* raw, const float* z_vals
 // combined with float atomics (256 contiguous bytes per wave instruction, the full-rate shape).
 struct GemmTN { const float* A; int lda; int No; const float* B; int ldb; int Ni; float* C; int ldc; float* bias; int64_t M; int64_t rows_per_wg; };
 
+#define GT_SLAB 32                     // rows per LDS slab = 16 k-steps
+// One workgroup (8 waves) owns a 256(o) x 256(i) block of C for its row slice; wave w owns the 32 x 256 strip
+// o in [32w, 32w+32) as 8 accumulator tiles.  A and B slabs of 32 rows are staged through LDS (coalesced
+// 4-byte loads with column/row masks, so unaligned narrow operands such as x[:, :63] with ld 90 need no
+// special case), double buffered: the next slab is fetched into registers while the current one feeds the
+// MFMAs, then written to the other buffer behind one barrier per slab.
 __global__ void __launch_bounds__(512, 2) gemm_tn_kernel(GemmTN P) {
-    const int lane = threadIdx.x & 63, i = lane & 31, hp = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float As[2][GT_SLAB][256];
+    __shared__ float Bs[2][GT_SLAB][256];
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int o0 = 32 * wv;
-    if (o0 >= P.No) return;
-    const int chunk = blockIdx.y;
-    const int i0 = 256 * chunk;
+    const bool strip = o0 < P.No;                    // waves without a strip still load and synchronise
+    const int i0 = 256 * blockIdx.y;
     const int nb = min(8, (P.Ni - i0 + 31) / 32);
     const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
     const int64_t m1 = min(P.M, m0 + P.rows_per_wg);
@@ -140,29 +147,46 @@ __global__ void __launch_bounds__(512, 2) gemm_tn_kernel(GemmTN P) {
     for (int b = 0; b < 8; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    const bool a_ok = (o0 + i) < P.No;
     float bsum = 0.f;
-    const float* Ap = P.A + o0 + i;
-    const float* Bp = P.B + i0 + i;
-    for (int64_t m = m0; m < m1; m += 8) {                 // 4 k-steps (8 rows) per trip
-        float a[4], bv[4][8];
+    // slab element e = t + 512 k  ->  row e / 256, column e % 256 (consecutive threads, consecutive columns)
+    const int lcol = t & 255, lrow0 = t >> 8;        // rows lrow0 + 2k
+    const bool a_col_ok = lcol < P.No, b_col_ok = (i0 + lcol) < P.Ni;
+    float ra[16], rb[16];
+    auto fetch = [&](int64_t m) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = m + 2 * u + hp;
-            const bool r_ok = row < m1;
-            a[u] = (r_ok && a_ok) ? Ap[row * P.lda] : 0.f;
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-                bv[u][b] = (r_ok && b < nb && (i0 + 32 * b + i) < P.Ni) ? Bp[row * P.ldb + 32 * b] : 0.f;
+        for (int k = 0; k < 16; ++k) {
+            const int64_t row = m + lrow0 + 2 * k;
+            const bool ok = row < m1;
+            ra[k] = (ok && a_col_ok) ? P.A[row * P.lda + lcol] : 0.f;
+            rb[k] = (ok && b_col_ok) ? P.B[row * P.ldb + i0 + lcol] : 0.f;
         }
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bsum += a[u];
+        for (int k = 0; k < 16; ++k) { As[buf][lrow0 + 2 * k][lcol] = ra[k]; Bs[buf][lrow0 + 2 * k][lcol] = rb[k]; }
+    };
+    fetch(m0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m = m0; m < m1; m += GT_SLAB) {
+        const bool more = (m + GT_SLAB) < m1;
+        if (more) fetch(m + GT_SLAB);                // in flight while this slab is consumed
+        if (strip) {
+#pragma unroll 4
+            for (int s = 0; s < GT_SLAB / 2; ++s) {
+                const float a = As[buf][2 * s + hp][o0 + i];
+                bsum += a;
 #pragma unroll
-            for (int b = 0; b < 8; ++b)
-                if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][b], acc[b], 0, 0, 0);
+                for (int b = 0; b < 8; ++b)
+                    if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][2 * s + hp][32 * b + i], acc[b], 0, 0, 0);
+            }
         }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
+    if (!strip) return;
     // C/D map: register r of lane (j = i, h = hp) is row o0 + frow(r,h), column i0 + 32b + j
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -174,9 +198,9 @@ __global__ void __launch_bounds__(512, 2) gemm_tn_kernel(GemmTN P) {
             if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
-    if (P.bias && chunk == 0) {
+    if (P.bias && blockIdx.y == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (hp == 0 && a_ok) atomicAdd(P.bias + o0 + i, bsum);
+        if (hp == 0 && (o0 + i) < P.No) atomicAdd(P.bias + o0 + i, bsum);
     }
 }
 
@@ -187,15 +211,14 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
         return sw_fail(SWNERF_E_ARG, "gemm_tn: bad arguments (M=%lld No=%d Ni=%d lda=%d ldb=%d ldc=%d)", (long long)M, No, Ni, lda, ldb, ldc);
     GemmTN P;
     P.A = A; P.lda = lda; P.No = No; P.B = B; P.ldb = ldb; P.Ni = Ni; P.C = C; P.ldc = ldc; P.bias = bias; P.M = M;
-    // split the rows over ~2 workgroups per CU, at least 512 rows each (multiple of 8)
-    int64_t nwg = (M + 511) / 512;
+    // split the rows over ~2 workgroups per CU, at least 256 rows each (whole slabs)
+    int64_t nwg = (M + 255) / 256;
     if (nwg > 512) nwg = 512;
     int64_t rows = (M + nwg - 1) / nwg;
-    rows = (rows + 7) / 8 * 8;
+    rows = (rows + GT_SLAB - 1) / GT_SLAB * GT_SLAB;
     P.rows_per_wg = rows;
     nwg = (M + rows - 1) / rows;
-    const int nstrips = (No + 31) / 32;
-    const dim3 grid((unsigned)nwg, (unsigned)((Ni + 255) / 256)), block(64 * nstrips);
+    const dim3 grid((unsigned)nwg, (unsigned)((Ni + 255) / 256)), block(512);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "gemm_tn launch");
 }

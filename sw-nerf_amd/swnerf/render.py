@@ -49,7 +49,12 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         input_dirs = viewdirs[:, None].expand(inputs.shape)
         input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
         embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
-    outputs_flat = batchify(fn, netchunk)(embedded)
+    if isinstance(fn, (vallina_NeRF,)) and fn._wants_grad():
+        # training: `netchunk` only bounds the reference's activation memory; one call lets
+        # the weight-gradient GEMMs run over all rows at once.  Results are identical either way.
+        outputs_flat = fn(embedded)
+    else:
+        outputs_flat = batchify(fn, netchunk)(embedded)
     return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
 
 
