@@ -8,6 +8,7 @@
 #include "../../include/swnerf.h"
 #include "swnerf_common.h"
 #include "host_util.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -126,81 +127,127 @@ extern "C" int swnerf_raw2outputs_backward(const float* raw, const float* z_vals
 struct GemmTN { const float* A; int lda; int No; const float* B; int ldb; int Ni; float* C; int ldc; float* bias; int64_t M; int64_t rows_per_wg; };
 
 #define GT_SLAB 32                     // rows per LDS slab = 16 k-steps
-// One workgroup (8 waves) owns a 256(o) x 256(i) block of C for its row slice; wave w owns the 32 x 256 strip
-// o in [32w, 32w+32) as 8 accumulator tiles.  A and B slabs of 32 rows are staged through LDS (coalesced
-// 4-byte loads with column/row masks, so unaligned narrow operands such as x[:, :63] with ld 90 need no
-// special case), double buffered: the next slab is fetched into registers while the current one feeds the
-// MFMAs, then written to the other buffer behind one barrier per slab.
-__global__ void __launch_bounds__(512, 2) gemm_tn_kernel(GemmTN P) {
-    __shared__ float As[2][GT_SLAB][256];
-    __shared__ float Bs[2][GT_SLAB][256];
+// One workgroup (8 waves) owns a 128(o) x 256(i) block of C for its row slice; wave w owns the 32 x 128 strip
+// o in [32(w&3), +32), i in [128(w>>2), +128) as 4 accumulator tiles.  A (32 x 128) and B (32 x 256) slabs are
+// staged through 48 KB of LDS, SINGLE buffered: load -> barrier -> MFMA -> barrier.  Overlap of memory and
+// matrix work comes from 2-3 co-resident workgroups per CU (one loads while another computes), not from a
+// register prefetch: hipcc spills a prefetched slab to scratch at this register budget (load -> vmcnt(0) ->
+// scratch_store), and scratch traffic shares vmcnt with everything else.
+// VEC4: both operands 16-byte aligned with column counts multiples of 4 (every 256/128-wide GEMM) -> float4
+// loads; otherwise 4-byte loads with column masks (x[:, :63] with ld 90, d_out[:, 3] with ld 4).
+template <bool VEC4>
+__global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
+    __shared__ __attribute__((aligned(16))) float As[GT_SLAB][128];
+    __shared__ __attribute__((aligned(16))) float Bs[GT_SLAB][256];
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int o0 = 32 * wv;
-    const bool strip = o0 < P.No;                    // waves without a strip still load and synchronise
-    const int i0 = 256 * blockIdx.y;
-    const int nb = min(8, (P.Ni - i0 + 31) / 32);
+    const int obase = 128 * (blockIdx.y & 1);        // which half of the (up to) 256 output rows
+    const int i0 = 256 * (blockIdx.y >> 1);
+    const int o0 = 32 * (wv & 3), ih = 128 * (wv >> 2);
+    const int nb = max(0, min(4, (P.Ni - i0 - ih + 31) / 32));
+    const bool strip = (obase + o0) < P.No && nb > 0;
     const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
-    const int64_t m1 = min(P.M, m0 + P.rows_per_wg);
-    f32x16 acc[8];
+    const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
+    f32x16 acc[4];
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     float bsum = 0.f;
-    // slab element e = t + 512 k  ->  row e / 256, column e % 256 (consecutive threads, consecutive columns)
-    const int lcol = t & 255, lrow0 = t >> 8;        // rows lrow0 + 2k
-    const bool a_col_ok = lcol < P.No, b_col_ok = (i0 + lcol) < P.Ni;
-    float ra[16], rb[16];
-    auto fetch = [&](int64_t m) {
+    const float* Ab = P.A + m0 * P.lda + obase;
+    const float* Bb = P.B + m0 * P.ldb + i0;
+    for (int mrel = 0; mrel < mlen; mrel += GT_SLAB) {
+        // ---- stage the slab.  All loads are UNCONDITIONAL (clamped addresses) and issued back to back; rows /
+        // columns outside the problem are zeroed at the LDS write.  (A load under `if` becomes a branch with its
+        // LDS write right behind it: one serialised memory round trip per load - measured 6 us per slab.)
+        const unsigned rlast = (unsigned)(mlen - 1 - mrel);
+        if (VEC4) {
+            f32x4 va[2], vb[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int64_t row = m + lrow0 + 2 * k;
-            const bool ok = row < m1;
-            ra[k] = (ok && a_col_ok) ? P.A[row * P.lda + lcol] : 0.f;
-            rb[k] = (ok && b_col_ok) ? P.B[row * P.ldb + i0 + lcol] : 0.f;
-        }
-    };
-    auto stash = [&](int buf) {
+            for (int k = 0; k < 2; ++k) {            // A: 32 x 128 floats = 1024 float4
+                const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
+                va[k] = *reinterpret_cast<const f32x4*>(Ab + (mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c4 < P.No) ? c4 : 0));
+            }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { As[buf][lrow0 + 2 * k][lcol] = ra[k]; Bs[buf][lrow0 + 2 * k][lcol] = rb[k]; }
-    };
-    fetch(m0);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t m = m0; m < m1; m += GT_SLAB) {
-        const bool more = (m + GT_SLAB) < m1;
-        if (more) fetch(m + GT_SLAB);                // in flight while this slab is consumed
-        if (strip) {
-#pragma unroll 4
-            for (int s = 0; s < GT_SLAB / 2; ++s) {
-                const float a = As[buf][2 * s + hp][o0 + i];
-                bsum += a;
+            for (int k = 0; k < 4; ++k) {            // B: 32 x 256 floats = 2048 float4
+                const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
+                vb[k] = *reinterpret_cast<const f32x4*>(Bb + (mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c4 < P.Ni) ? c4 : 0));
+            }
+            const f32x4 z = {};
 #pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][2 * s + hp][32 * b + i], acc[b], 0, 0, 0);
+            for (int k = 0; k < 2; ++k) {
+                const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
+                *reinterpret_cast<f32x4*>(&As[row][c4]) = ((unsigned)row <= rlast && obase + c4 < P.No) ? va[k] : z;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
+                *reinterpret_cast<f32x4*>(&Bs[row][c4]) = ((unsigned)row <= rlast && i0 + c4 < P.Ni) ? vb[k] : z;
+            }
+        } else {
+            float va[8], vb[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = t + 512 * k, row = f >> 7, c = f & 127;
+                va[k] = Ab[(mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c < P.No) ? c : 0)];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int f = t + 512 * k, row = f >> 8, c = f & 255;
+                vb[k] = Bb[(mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c < P.Ni) ? c : 0)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = t + 512 * k, row = f >> 7, c = f & 127;
+                As[row][c] = ((unsigned)row <= rlast && obase + c < P.No) ? va[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int f = t + 512 * k, row = f >> 8, c = f & 255;
+                Bs[row][c] = ((unsigned)row <= rlast && i0 + c < P.Ni) ? vb[k] : 0.f;
             }
         }
-        if (more) stash(buf ^ 1);
         __syncthreads();
-        buf ^= 1;
+        if (strip) {
+            if (nb == 4) {                           // full-width strip: batched LDS reads, branch-free MFMA groups
+#pragma unroll 4
+                for (int s = 0; s < GT_SLAB / 2; ++s) {
+                    const float a = As[2 * s + hp][o0 + i];
+                    float bv[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bv[b] = Bs[2 * s + hp][ih + 32 * b + i];
+                    bsum += a;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[b], acc[b], 0, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < GT_SLAB / 2; ++s) {
+                    const float a = As[2 * s + hp][o0 + i];
+                    bsum += a;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[2 * s + hp][ih + 32 * b + i], acc[b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
     }
     if (!strip) return;
-    // C/D map: register r of lane (j = i, h = hp) is row o0 + frow(r,h), column i0 + 32b + j
+    // C/D map: register r of lane (j = i, h = hp) is row obase + o0 + frow(r,h), column i0 + ih + 32b + j
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < 4; ++b) {
         if (b >= nb) continue;
-        const int col = i0 + 32 * b + i;
+        const int col = i0 + ih + 32 * b + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = o0 + sw_frow(r, hp);
+            const int o = obase + o0 + sw_frow(r, hp);
             if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
-    if (P.bias && blockIdx.y == 0) {
+    if (P.bias && (blockIdx.y >> 1) == 0 && ih == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (hp == 0 && (o0 + i) < P.No) atomicAdd(P.bias + o0 + i, bsum);
+        if (hp == 0 && (obase + o0 + i) < P.No) atomicAdd(P.bias + obase + o0 + i, bsum);
     }
 }
 
@@ -218,7 +265,11 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
     rows = (rows + GT_SLAB - 1) / GT_SLAB * GT_SLAB;
     P.rows_per_wg = rows;
     nwg = (M + rows - 1) / rows;
-    const dim3 grid((unsigned)nwg, (unsigned)((Ni + 255) / 256)), block(512);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, (hipStream_t)stream, P);
+    if (rows * (int64_t)(lda > ldb ? lda : ldb) >= (1LL << 31)) return sw_fail(SWNERF_E_UNSUPP, "gemm_tn: row slice too large for 32-bit offsets");
+    const dim3 grid((unsigned)nwg, (unsigned)(((Ni + 255) / 256) * (No > 128 ? 2 : 1))), block(512);
+    const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && (No % 4 == 0) && (Ni % 4 == 0) &&
+                      (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+    if (vec4) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "gemm_tn launch");
 }
