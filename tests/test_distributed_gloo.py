@@ -38,11 +38,17 @@ def _worker(rank, world, port, q):
     a = torch.full((5, 3), float(rank))
     same = parallel.gather_pixels(a)
     rag = parallel.gather_pixels(torch.full((3 + rank, 2), float(rank)), counts=[3 + r for r in range(world)])
+    # data-parallel training: one flat all-reduce of the gradients (each rank saw half of the rays)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    for k, p_ in enumerate(lin.parameters()):
+        p_.grad = torch.full_like(p_, float(rank + 1) * (k + 1))
+    parallel.allreduce_gradients([lin, None])
+    grads_ok = all(bool(torch.all(p_.grad == 1.5 * (k + 1))) for k, p_ in enumerate(lin.parameters()))
     # the bench's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        q.put((img.numpy(), render_range(0, H * W).reshape(H, W, 5).numpy(), same.numpy(), rag.numpy(), float(t)))
+        q.put((img.numpy(), render_range(0, H * W).reshape(H, W, 5).numpy(), same.numpy(), rag.numpy(), float(t), grads_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,7 +61,7 @@ def test_sharded_render_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    img, ref, same, rag, tmax = q.get(timeout=240)
+    img, ref, same, rag, tmax, grads_ok = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -63,4 +69,4 @@ def test_sharded_render_gloo_world2():
     np.testing.assert_allclose(img, ref, atol=2e-6, equal_nan=True)      # (sgemm blocking differs with the row count)
     assert np.array_equal(same[:5], np.zeros((5, 3))) and np.array_equal(same[5:], np.ones((5, 3)))
     assert rag.shape == (7, 2) and np.array_equal(rag[:3], np.zeros((3, 2))) and np.array_equal(rag[3:], np.ones((4, 2)))
-    assert tmax == 2.0
+    assert tmax == 2.0 and grads_ok
