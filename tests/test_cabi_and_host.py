@@ -102,6 +102,23 @@ def test_module_parameter_names_and_shapes(built):
 
 
 def test_fused_dispatch_detection(built):
+    with torch.no_grad():
+        _fused_dispatch_detection()
+    # with autograd on and trainable parameters render_rays must take the differentiable op path
+    from swnerf import embedder, model, render
+    e10, c10 = embedder.get_embedder(10, 3, 0)
+    e4, c4 = embedder.get_embedder(4, 3, 0)
+    net = model.vallina_NeRF(D=8, W=256, input_ch=c10, input_ch_views=c4, output_ch=5, skips=[4], use_viewdirs=True)
+    tagged = lambda a, b, c: None
+    tagged.swnerf_embedders = {"embed_fn": e10, "embeddirs_fn": e4}
+    with torch.enable_grad():
+        assert render.fused_plan(tagged, [net]) is None
+        for p in net.parameters():
+            p.requires_grad_(False)
+        assert render.fused_plan(tagged, [net]) == (10, 4, 0)
+
+
+def _fused_dispatch_detection():
     from swnerf import embedder, model, render, render_dnerf
     e10, c10 = embedder.get_embedder(10, 3, 0)
     e4, c4 = embedder.get_embedder(4, 3, 0)

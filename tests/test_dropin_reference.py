@@ -61,7 +61,11 @@ def test_static_runner_resolves_to_this_build(tmp_path):
     assert isinstance(kw_test["network_fn"], swnerf.model.vallina_NeRF) and isinstance(kw_test["network_fine"], swnerf.model.vallina_NeRF)
     assert len(grad_vars) == 48 and start == 0
     # the reference's own lambda is recognised -> render_rays would take the fused pass
-    assert swnerf.render.fused_plan(kw_test["network_query_fn"], [kw_test["network_fn"], kw_test["network_fine"]]) == (10, 4, 0)
+    import torch
+    with torch.no_grad():        # render_only / test-time rendering (nerf/run.py:566-571)
+        assert swnerf.render.fused_plan(kw_test["network_query_fn"], [kw_test["network_fn"], kw_test["network_fine"]]) == (10, 4, 0)
+    with torch.enable_grad():    # train(): trainable parameters -> the differentiable op path
+        assert swnerf.render.fused_plan(kw_train["network_query_fn"], [kw_train["network_fn"], kw_train["network_fine"]]) is None
     assert kw_test["perturb"] is False and kw_test["raw_noise_std"] == 0.
     # kwargs of the reference's render_rays == ours (level-2 patch is signature-compatible)
     import inspect
@@ -85,7 +89,9 @@ def test_dnerf_runner_resolves_to_this_build(tmp_path):
     kw_train, kw_test, start, grad_vars, opt = drun.create_nerf(args)
     net = kw_test["network_fn"]
     assert isinstance(net, swnerf.model.DirectTemporalNeRF) and kw_test["network_fine"] is None
-    assert swnerf.render.fused_plan(kw_test["network_query_fn"], [net, None], need_time=True) == (10, 4, 10)
+    import torch
+    with torch.no_grad():
+        assert swnerf.render.fused_plan(kw_test["network_query_fn"], [net, None], need_time=True) == (10, 4, 10)
     assert list(inspect.signature(drun.render_rays).parameters) == list(inspect.signature(swnerf.render_dnerf.render_rays).parameters)
     assert list(inspect.signature(drun.render).parameters) == list(inspect.signature(swnerf.render_dnerf.render).parameters)
     assert list(inspect.signature(drun.run_network).parameters) == list(inspect.signature(swnerf.render_dnerf.run_network).parameters)
