@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libswnerf_hip.so is built in-tree (it travels to the GPU box with the snapshot); rebuild it here if it
+    is missing or older than its sources, so a fresh checkout can run either suite directly."""
+    import __graft_entry__
+    __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
