@@ -156,6 +156,29 @@ __device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[
     ws.base += NS * 1024;
 }
 
+// ---- 1- and 3-output heads on the VALU ---------------------------------------------------------------
+// res[o] = sum_f W[o][f] * x[f]  over the NT*32 features of a row.  Lane (j,h) holds the 16*NT features
+// 32n + frow(r,h) of row j in x[n][r]; W[o] is stored like a bias vector (tile n: [h][r]), so each lane
+// multiplies what it holds and the two halves of a row are added with one cross-half exchange.
+// On return every lane (both halves) has the full sums.  Consumes NOUT*NT bias tiles.
+template <int NOUT, int NT>
+__device__ __forceinline__ void head_valu(const f32x16 (&x)[NT], WStream& ws, float (&res)[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(ws.bias + (o * NT + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                acc = fmaf(w[0], x[n][4 * g + 0], acc); acc = fmaf(w[1], x[n][4 * g + 1], acc);
+                acc = fmaf(w[2], x[n][4 * g + 2], acc); acc = fmaf(w[3], x[n][4 * g + 3], acc);
+            }
+        res[o] = acc + __shfl_xor(acc, 32, 64);
+    }
+    ws.bias += NOUT * NT * SW_BIAS_TILE_FLOATS;
+}
+
 // ---- activation tiles <-> row-major [M, ld] buffers (training path) ------------------------------
 // register r = 4g+e of lane (j,h) of tile n is feature 32n + 8g + 4h + e of row j: 16 contiguous bytes
 template <int NT>
@@ -237,15 +260,41 @@ __device__ __forceinline__ void pe_time(float t, int h, f32x16& e) {
     }
 }
 
+// The 2 embedding k-tiles are needed at layer 0 and again at the skip layer 5.  Keeping 32 registers alive
+// across layers 1..4 tips this kernel into spilling (and a scratch reload inside a segment drains the DMA
+// ring: scratch shares vmcnt), so they are parked in the wave's LDS slice [r][lane] in between.
+#define SW_EMB_LDS_FLOATS (3 * 16 * 64)          // per wave: 2 position tiles + 1 view-direction tile
+__device__ __forceinline__ void emb_park(float* lds_emb, int lane, const f32x16 (&e)[2]) {
+#pragma unroll
+    for (int a = 0; a < 32; ++a) lds_emb[a * 64 + lane] = e[a >> 4][a & 15];
+}
+__device__ __forceinline__ void emb_fetch(const float* lds_emb, int lane, f32x16 (&e)[2]) {
+#pragma unroll
+    for (int a = 0; a < 32; ++a) e[a >> 4][a & 15] = lds_emb[a * 64 + lane];
+}
+
+// the view-direction tile is a per-ray constant: left in registers the compiler hoists it out of the tile
+// loop, keeps 16 registers alive for the whole ray and spills them into the VIEWS segment.
+__device__ __forceinline__ void tile_park(float* lds_tile, int lane, const f32x16& e) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) lds_tile[a * 64 + lane] = e[a];
+}
+__device__ __forceinline__ void tile_fetch(const float* lds_tile, int lane, f32x16& e) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) e[a] = lds_tile[a * 64 + lane];
+}
+
 // ---- one trunk pass: 8 layers of width 256 with the skip at layer 5 ----------------------
 // deform_pass: layer 0 also takes the time-embedding k-tile (model.py:129: cat[new_pts, t]).
-// Returns with `in` = relu(layer-7 output) and `head` = the 1-tile head applied to it
-// (alpha_linear for the canonical net, _time_out for the deformation net).
+// Returns with `in` = relu(layer-7 output) and head[0..2] = the head applied to it on every lane:
+// alpha_linear (head[0] = sigma) for the canonical net, _time_out (dx) for the deformation net.
 // TRAIN: also stores every layer's post-ReLU activation to act[arow][256*l ...] (row-major, ld SW_ACT_LD).
 template <bool DNERF, bool TRAIN = false>
-__device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool deform_pass, int h,
-                                           f32x16 (&in)[8], f32x16 (&out)[8], f32x16& head, WStream& ws,
+__device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_emb, float t, bool deform_pass, int h,
+                                           f32x16 (&in)[8], f32x16 (&out)[8], float (&head)[3], WStream& ws,
                                            float* act = nullptr, int64_t arow = 0, bool alive = false) {
+    const int lane_ = threadIdx.x & 63;
+    emb_park(lds_emb, lane_, emb);
 #pragma nounroll
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
@@ -259,7 +308,11 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool
             }
         } else {
             seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
-            if (l == 5) seg_mfma<8, 2, SEG_ACC>(out, emb, ws);   // skip: cat[input_pts, h] (model.py:45-46)
+            if (l == 5) {                                        // skip: cat[input_pts, h] (model.py:45-46)
+                f32x16 e2[2];
+                emb_fetch(lds_emb, lane_, e2);
+                seg_mfma<8, 2, SEG_ACC>(out, e2, ws);
+            }
         }
 #pragma unroll
         for (int n = 0; n < 8; ++n)
@@ -267,27 +320,36 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float t, bool
             for (int r = 0; r < 16; ++r) in[n][r] = fmaxf(out[n][r], 0.f);
         if (TRAIN) tiles_store<8>(act + 256 * l, arow, SW_ACT_LD, alive, h, in);   // h_l, post-ReLU
     }
-    f32x16 hd[1];
-    seg_mfma<1, 8, SEG_BIAS>(hd, in, ws);
-    head = hd[0];
+    // head biases: one tile right behind the weight tiles, the same 16 floats in both lane halves:
+    // [b_alpha, b_r, b_g, b_b] (canonical) / [b_dx0, b_dx1, b_dx2] (deformation)
+    if (DNERF && deform_pass) {
+        head_valu<3, 8>(in, ws, head);
+        head[0] += ws.bias[0]; head[1] += ws.bias[1]; head[2] += ws.bias[2];
+    } else {
+        float s1[1];
+        head_valu<1, 8>(in, ws, s1);
+        head[0] = s1[0] + ws.bias[0]; head[1] = 0.f; head[2] = 0.f;
+    }
+    ws.bias += SW_BIAS_TILE_FLOATS;
 }
 
 // ---- canonical tail: feature_linear (no activation) -> views_linears[0]+relu -> rgb_linear ---
-// `in` = relu(layer 7).  On return rgb[0..2] of lane half 0 = raw rgb of row j (model.py:49-58).
-__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[8], float d0, float d1, float d2,
-                                           int h, f32x16& rgb, WStream& ws) {
+// `in` = relu(layer 7).  On return rgb[0..2] = raw rgb of row j on every lane (model.py:49-58).
+// hb_rgb: the head-bias tile (LDS) saved by the caller before FEAT: [b_alpha, b_r, b_g, b_b].
+// demb: the view-direction k-tile (pe_dir), supplied by the caller.
+__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[8], const f32x16& demb,
+                                           float (&rgb)[3], const float* hb_rgb, WStream& ws) {
     seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                  // feature = feature_linear(h)
     f32x16 k9[9];
 #pragma unroll
     for (int n = 0; n < 8; ++n) k9[n] = out[n];
-    pe_dir(d0, d1, d2, h, k9[8]);                           // cat[feature, input_views]
+    k9[8] = demb;                                           // cat[feature, input_views]
     f32x16 hv[4];
     seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
-    f32x16 o[1];
-    seg_mfma<1, 4, SEG_BIAS>(o, hv, ws);
-    rgb = o[0];
+    head_valu<3, 4>(hv, ws, rgb);
+    rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
 }

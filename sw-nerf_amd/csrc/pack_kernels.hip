@@ -63,6 +63,14 @@ __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
     }
 }
 
+// head-bias tile: [h][r] = (b_a ++ b_b)[r] for r < n_a + n_b, the same in both lane halves, else 0
+__global__ void pack_headbias_kernel(float* dst, const float* b_a, int n_a, const float* b_b, int n_b) {
+    const int e = threadIdx.x;
+    if (e >= SW_BIAS_TILE_FLOATS) return;
+    const int r = e & 15;
+    dst[e] = r < n_a ? b_a[r] : ((r - n_a) < n_b ? b_b[r - n_a] : 0.f);
+}
+
 struct Packer {
     hipStream_t st; float* w; float* b; int Lp, Ld, Lt; int rc;
     void seg(const float* W, const float* bias, int out_dim, int in_dim, int NT, int KT, const int* kt, const int* kb) {
@@ -91,8 +99,27 @@ struct Packer {
         w += total;
         if (has_bias) b += NT * SW_BIAS_TILE_FLOATS;
     }
-    // one 8-layer trunk + 1-tile head; P = {W0,b0,...,W7,b7}, head = {Wh,bh}
-    void trunk(const float* const* P, const float* Wh, const float* bh, int head_out, int Cpos, int Ctime) {
+    // `nout` weight rows of length `in_dim` (a multiple of 32) as bias-style tiles, for head_valu
+    void vecs(const float* W, int nout, int in_dim) {
+        for (int o = 0; o < nout && !rc; ++o) {
+            PackSeg s;
+            s.W = W; s.b = W + (size_t)o * in_dim; s.out_dim = in_dim; s.in_dim = in_dim; s.NT = in_dim / 32; s.KT = 0;
+            for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
+            s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0;
+            hipLaunchKernelGGL(pack_seg_kernel, dim3((s.NT * SW_BIAS_TILE_FLOATS + 255) / 256), dim3(256), 0, st, s);
+            rc = sw_check(hipGetLastError(), "pack_net launch");
+            b += s.NT * SW_BIAS_TILE_FLOATS;
+        }
+    }
+    void headbias(const float* b_a, int n_a, const float* b_b, int n_b) {
+        if (rc) return;
+        hipLaunchKernelGGL(pack_headbias_kernel, dim3(1), dim3(64), 0, st, b, b_a, n_a, b_b, n_b);
+        rc = sw_check(hipGetLastError(), "pack_net launch");
+        b += SW_BIAS_TILE_FLOATS;
+    }
+    // one 8-layer trunk; P = {W0,b0,...,W7,b7}.  The head (Wh [head_out,256], bh) goes to the bias tiles.
+    void trunk(const float* const* P, const float* Wh, const float* bh, int head_out, int Cpos, int Ctime,
+               const float* bh2 = nullptr, int n2 = 0) {
         const int t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int b8[8];
         for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
@@ -109,7 +136,8 @@ struct Packer {
                 seg(P[2 * l], P[2 * l + 1], 256, 256, 8, 8, t8, b8);
             }
         }
-        seg(Wh, bh, head_out, 256, 1, 8, t8, b8);
+        vecs(Wh, head_out, 256);
+        headbias(bh, head_out, bh2, n2);
     }
 };
 
@@ -130,10 +158,10 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     for (int i = 0; i < 8; ++i) { vt[i] = KT_TRUNK; vb[i] = 32 * i; }
     vt[8] = KT_DIR; vb[8] = 256;
     auto canon = [&](Packer& pk) {
-        pk.trunk(params, params[20], params[21], 1, Cpos, 0);                      // ... ALPHA
+        pk.trunk(params, params[20], params[21], 1, Cpos, 0, params[23], 3);       // ... alpha_linear + head biases
         pk.seg(params[18], params[19], 256, 256, 8, 8, t8, b8);                    // FEAT
         pk.seg(params[16], params[17], 128, 256 + Cdir, 4, 9, vt, vb);             // VIEWS
-        pk.seg(params[22], params[23], 3, 128, 1, 4, t8, b8);                      // RGB
+        pk.vecs(params[22], 3, 128);                                               // rgb_linear.weight
     };
     auto tail = [&](float* wbase, const float* head) {
         return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
@@ -158,7 +186,6 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     // the view branch once more, as a stream that wraps onto itself (biases: the tiles packed above)
     Packer vl{st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time, 0};
     vl.seg(params[16], nullptr, 128, 256 + Cdir, 4, 9, vt, vb);
-    vl.seg(params[22], nullptr, 3, 128, 1, 4, t8, b8);
     if (vl.rc) return vl.rc;
     return tail(vl.w, packed + SW_CANON_VL_OFFSET);
 }

@@ -27,7 +27,7 @@ struct PassDev {
     int sort_n;             // power of two >= S + n_importance
 };
 #define SW_LDS_BIAS_FLOATS ((SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
-#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS)            // per wave
+#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS)   // per wave: weight ring + parked embedding
 #define SW_LDS_FIXED_FLOATS (SW_LDS_BIAS_FLOATS + 4 * SW_LDS_RING_FLOATS)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     if (ray >= a.n_rays) return;                 // wave-uniform
     const float* lds_bias = lds_all;
     float* lds_ring = lds_all + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
     float* lds = lds_all + SW_LDS_FIXED_FLOATS + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
     float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
@@ -86,6 +87,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const float v0 = rb[a.cols - 3], v1 = rb[a.cols - 2], v2 = rb[a.cols - 1];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
 
+    {   // once per ray: the view-direction encoding, parked in LDS (see tile_park)
+        f32x16 demb;
+        pe_dir(v0, v1, v2, h, demb);
+        tile_park(lds_emb + 2 * 16 * 64, lane, demb);
+    }
     WStream ws;
     ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
@@ -102,15 +108,16 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         // pts = rays_o + rays_d * z  (two roundings, nerf/run.py:385)
         float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
 
-        f32x16 emb[2], in[8], out[8], head, rgb;
+        f32x16 emb[2], in[8], out[8];
+        float head[3], rgb[3];
         pe_pos(px, py, pz, h, emb);
         if (DNERF) {
 #pragma nounroll
             for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
-                trunk_pass<true>(emb, ft, pass == 0, h, in, out, head, ws);
+                trunk_pass<true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws);
                 if (pass == 0) {
-                    // dx = _time_out(h): rows sit on lane half 0, registers 0..2 (model.py:136,146-149)
-                    const float ex = __shfl(head[0], j), ey = __shfl(head[1], j), ez = __shfl(head[2], j);
+                    // dx = _time_out(h) (model.py:136,146-149)
+                    const float ex = head[0], ey = head[1], ez = head[2];
                     if (a.dx && live && h == 0) {
                         float* o = a.dx + (ray * S + s) * 3;
                         o[0] = ex; o[1] = ey; o[2] = ez;
@@ -124,14 +131,18 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                 o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;                          // model.py:144-145
             }
         } else {
-            trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+            trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
         }
-        canon_tail(in, out, v0, v1, v2, h, rgb, ws);
+        {
+            f32x16 demb;
+            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+            canon_tail(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
+        }
         ws_rewind(ws, P.w0, lds_bias, lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
-        const float c0 = __shfl(rgb[0], j), c1 = __shfl(rgb[1], j), c2 = __shfl(rgb[2], j);
-        float sg = __shfl(head[0], j);
+        const float c0 = rgb[0], c1 = rgb[1], c2 = rgb[2];
+        float sg = head[0];
         if (a.raw && live && h == 0) {
             f32x4 r4 = {c0, c1, c2, sg};
             *reinterpret_cast<f32x4*>(a.raw + (ray * S + s) * 4) = r4;
@@ -267,6 +278,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     extern __shared__ __attribute__((aligned(16))) float lds_bias[];
     float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
     bias_to_lds(lds_bias, P.b0, P.nbias);
     if (tile * 32 >= P.M) return;
@@ -274,7 +286,8 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     const bool live = row < P.M;
     const float* xr = P.x + (live ? row : P.M - 1) * P.C;
 
-    f32x16 emb[2], in[8], out[8], head, rgb;
+    f32x16 emb[2], in[8], out[8];
+    float head[3], rgb[3];
 #pragma unroll
     for (int a = 0; a < 32; ++a) {
         const int col = sw_pos_col(a, h, P.Lp);
@@ -287,16 +300,17 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
         const float ft = P.t_emb ? P.t_emb[(live ? row : P.M - 1) * P.Ct] : 0.f;   // column 0 of gamma(t) is t
 #pragma nounroll
         for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
-            trunk_pass<true>(emb, ft, pass == 0, h, in, out, head, ws);
+            trunk_pass<true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws);
             if (pass == 0) {
-                ex = __shfl(head[0], j); ey = __shfl(head[1], j); ez = __shfl(head[2], j);
+                ex = head[0]; ey = head[1]; ez = head[2];
                 pe_pos(xr[0] + ex, xr[1] + ey, xr[2] + ez, h, emb);      // embed_fn(input_pts_orig + dx)
             }
         }
     } else {
-        trunk_pass<false, TRAIN>(emb, 0.f, false, h, in, out, head, ws, P.act, row, live);
+        trunk_pass<false, TRAIN>(emb, lds_emb, 0.f, false, h, in, out, head, ws, P.act, row, live);
     }
     // view-direction features: gathered like the position ones
+    const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
     f32x16 k9[9];
     seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
     if (TRAIN) tiles_store<8>(P.act + SW_ACT_FEAT, row, SW_ACT_LD, live, h, out);
@@ -314,9 +328,8 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
     if (TRAIN) tiles_store<4>(P.act + SW_ACT_HV, row, SW_ACT_LD, live, h, hv);
-    f32x16 o1[1];
-    seg_mfma<1, 4, SEG_BIAS>(o1, hv, ws);
-    rgb = o1[0];
+    head_valu<3, 4>(hv, ws, rgb);
+    rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
     if (live && h == 0) {
         f32x4 r4 = {rgb[0], rgb[1], rgb[2], head[0]};
         *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
@@ -337,17 +350,20 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
     bias_to_lds(lds_bias, P.b0, P.nbias);
     if (tile * 32 >= P.M) return;
     const int64_t row = tile * 32 + j;
     const bool live = row < P.M;
     const int64_t rr = live ? row : P.M - 1;
-    f32x16 emb[2], in[8], out[8], head;
+    f32x16 emb[2], in[8], out[8];
+    float head[3];
     pe_pos(P.pts[rr * 3], P.pts[rr * 3 + 1], P.pts[rr * 3 + 2], h, emb);
     WStream ws;
     ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-    trunk_pass<false>(emb, 0.f, false, h, in, out, head, ws);
+    trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
+    const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
     seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                   // feature = feature_linear(h)
     // the ring now holds the first VIEWS steps; the views-loop region starts with the same ones
     ws.base = reinterpret_cast<const char*>(P.wvl);
@@ -367,9 +383,9 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
-        f32x16 o1[1];
-        seg_mfma<1, 4, SEG_BIAS>(o1, hv, ws);
-        sr += o1[0][0]; sg += o1[0][1]; sb += o1[0][2];
+        float c3[3];
+        head_valu<3, 4>(hv, ws, c3);
+        sr += c3[0] + hb_rgb[1]; sg += c3[1] + hb_rgb[2]; sb += c3[2] + hb_rgb[3];
         ws.base = reinterpret_cast<const char*>(P.wvl);      // the region's tail is its own head
     }
     if (live && h == 0) {
@@ -395,6 +411,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_dx_kernel(DxDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
     bias_to_lds(lds_bias, P.b0, SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS);
     if (tile * 32 >= P.M) return;

@@ -21,27 +21,30 @@
 #define SW_STEPS_EMB    64        // 8 n-tiles x 2 pos-emb k-tiles
 #define SW_STEPS_EMB_T  96        // 8 x 3 (pos emb + time emb): deformation layer 0
 #define SW_STEPS_TRUNK  256       // 8 x 8
-#define SW_STEPS_HEAD   32        // 1 x 8   (alpha_linear / _time_out)
 #define SW_STEPS_VIEWS  144       // 4 x 9   (feature 8 tiles + dir emb 1 tile)
-#define SW_STEPS_RGB    16        // 1 x 4
-// canonical net stream: L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | ALPHA | FEAT | VIEWS | RGB
+// The 1- and 3-output heads (alpha_linear, rgb_linear, _time_out) are NOT in the MFMA stream: a 32-wide
+// padded tile would spend 128 / 64 MFMAs on 1 / 3 useful rows.  They are VALU dot products over the
+// features a lane already holds (mlp_core.h head_valu); their weights sit with the biases in LDS.
+// canonical net stream: L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | FEAT | VIEWS
 #define SW_CANON_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
-                        2 * SW_STEPS_TRUNK + SW_STEPS_HEAD + SW_STEPS_TRUNK + SW_STEPS_VIEWS + SW_STEPS_RGB)
-#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 1 + 8 + 4 + 1)
-// deformation net stream: D0 | D1..D4 | D5(trunk) D5(emb) | D6 D7 | DOUT
-#define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
-                         2 * SW_STEPS_TRUNK + SW_STEPS_HEAD)
-#define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 1)
+                        2 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_VIEWS)
+// "bias" tiles of 32 floats ([h][r], the accumulator-init layout) in consumption order:
+//   L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8, then 1 tile of head biases (alpha, r, g, b) |
+//   FEAT 8 | VIEWS 4 | rgb_linear.weight 3 x 4
+#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 8 + 4 + 12)
+#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 8 + 1 + 8)   // index of the first views_linears bias tile
+// deformation net stream: D0 | D1..D4 | D5(trunk) D5(emb) | D6 D7 ;  bias tiles: 64 | _time_out.weight 3 x 8 | 1 head-bias tile
+#define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
+#define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 24 + 1)
 
 // blob CANON : [canon steps][ring tail = copy of first SW_RING steps][canon bias][views loop]
-// views loop  : [VIEWS steps][RGB steps][tail = copy of the first SW_RING VIEWS steps] - the view
+// views loop  : [VIEWS steps][tail = copy of the first SW_RING VIEWS steps] - the view
 //               branch as a stream that wraps onto itself, for queries of many view directions per
 //               point (swnerf_query_points: trunk and density once, view branch V times)
 #define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
 #define SW_CANON_VL_OFFSET  (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
-#define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_STEPS_RGB + SW_RING) * SW_STEP_FLOATS)
+#define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_RING) * SW_STEP_FLOATS)
 #define SW_CANON_FLOATS     (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
-#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 1 + 8)   // index of the first views_linears bias tile
 // blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
 // (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
 #define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
