@@ -156,6 +156,15 @@ __device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[
     ws.base += NS * 1024;
 }
 
+// ReLU as ONE v_max_f32: fmaxf(x, 0.f) costs two (hipcc first canonicalises x with v_max x,x because IEEE
+// mode must quiet signalling NaNs; it folds a med3 clamp back into the same pair).  Plain VALU, so the
+// statement needs no counters or wait states; not volatile, the scheduler may move it.
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 // ---- 1- and 3-output heads on the VALU ---------------------------------------------------------------
 // res[o] = sum_f W[o][f] * x[f]  over the NT*32 features of a row.  Lane (j,h) holds the 16*NT features
 // 32n + frow(r,h) of row j in x[n][r]; W[o] is stored like a bias vector (tile n: [h][r]), so each lane
@@ -317,7 +326,7 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
 #pragma unroll
         for (int n = 0; n < 8; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) in[n][r] = fmaxf(out[n][r], 0.f);
+            for (int r = 0; r < 16; ++r) in[n][r] = relu1(out[n][r]);
         if (TRAIN) tiles_store<8>(act + 256 * l, arow, SW_ACT_LD, alive, h, in);   // h_l, post-ReLU
     }
     // head biases: one tile right behind the weight tiles, the same 16 floats in both lane halves:
@@ -349,7 +358,7 @@ __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
     head_valu<3, 4>(hv, ws, rgb);
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
 }

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
     if (TRAIN) tiles_store<4>(P.act + SW_ACT_HV, row, SW_ACT_LD, live, h, hv);
     head_valu<3, 4>(hv, ws, rgb);
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hv[n][r] = fmaxf(hv[n][r], 0.f);
+            for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
         float c3[3];
         head_valu<3, 4>(hv, ws, c3);
         sr += c3[0] + hb_rgb[1]; sg += c3[1] + hb_rgb[2]; sb += c3[2] + hb_rgb[3];
