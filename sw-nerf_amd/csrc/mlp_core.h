@@ -99,15 +99,42 @@ __device__ __forceinline__ void ws_rewind(WStream& ws, const float* w, const flo
     ws.bias = lds_bias + (lane >> 5) * 16;
 }
 
-template <int S, int NS, int NT, int KT>
-__device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws) {
+enum { SEG_ACC = 0, SEG_BIAS = 1, SEG_ZERO = 2, SEG_BIAS_SCALED = 3 };
+// accumulator-init values of output tile n (bias tile n of the segment) for this lane half
+template <int INIT>
+__device__ __forceinline__ void seg_init_read(f32x16& b, const WStream& ws, int n) {
+    if constexpr (INIT == SEG_BIAS || INIT == SEG_BIAS_SCALED) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws.bias + n * SW_BIAS_TILE_FLOATS + 4 * g);
+            b[4 * g + 0] = v[0]; b[4 * g + 1] = v[1]; b[4 * g + 2] = v[2]; b[4 * g + 3] = v[3];
+        }
+    }
+}
+
+template <int S, int NS, int NT, int KT, int INIT>
+__device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, f32x16& binit, float scale) {
     if constexpr (S < NS) {
         constexpr int n = S / (KT * 4), kt = (S / 4) % KT, q = S % 4;
         constexpr int slot = S % SW_RING, nslot = (S + 1) % SW_RING;
+        constexpr bool tile_first = (S % (KT * 4)) == 0, tile_last = ((S + 1) % (KT * 4)) == 0;
+        if constexpr (tile_first) {
+            // The init values were read from LDS one step ago (or by seg_mfma for tile 0): only ONE tile of
+            // them is ever live.  Reading all NT tiles up front keeps 16*NT more accumulator registers busy
+            // (the first MFMA of a tile takes them as srcC and writes a different dst), which is what pushed
+            // the per-ray state of the render kernel into scratch.
+            if constexpr (INIT == SEG_BIAS) out[n] = binit;
+            else if constexpr (INIT == SEG_BIAS_SCALED) out[n] = binit * scale;
+            else if constexpr (INIT == SEG_ZERO) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[n][r] = 0.f;
+            }
+        }
         // steps S+1 .. S+SW_RING-1 are in flight: retire the oldest and read it one step ahead
         ws_wait<SW_RING - 2>();
         const f32x4 a_next = ws_read(ws, nslot);
-        __builtin_amdgcn_sched_barrier(0);       // keep the ds_read AHEAD of this step's MFMAs
+        if constexpr (tile_last && n + 1 < NT) seg_init_read<INIT>(binit, ws, n + 1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the ds_reads AHEAD of this step's MFMAs
         const f32x4 a = ws.a_cur;
         out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], kin[kt][4 * q + 0], out[n], 0, 0, 0);
         out[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], kin[kt][4 * q + 1], out[n], 0, 0, 0);
@@ -117,7 +144,7 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
         // refill the slot of step S (read during step S-1) with step S + SW_RING
         ws_dma(ws.base + (S + SW_RING) * 1024, ws.voff, ws.lds_addr + slot * 1024);
         ws.a_cur = a_next;
-        seg_steps<S + 1, NS, NT, KT>(out, kin, ws);
+        seg_steps<S + 1, NS, NT, KT, INIT>(out, kin, ws, binit, scale);
     }
 }
 
@@ -125,34 +152,14 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
 // INIT: how the accumulators start -
 //   SEG_ACC (false) keep accumulating | SEG_BIAS (true) the bias tile (so no separate bias pass) |
 //   SEG_ZERO zeros | SEG_BIAS_SCALED the bias tile times a per-lane scalar (backward: w_alpha * d sigma)
-enum { SEG_ACC = 0, SEG_BIAS = 1, SEG_ZERO = 2, SEG_BIAS_SCALED = 3 };
 template <int NT, int KT, int INIT>
 __device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, float scale = 1.f) {
     constexpr int NS = NT * KT * 4;
     static_assert(NS % SW_RING == 0, "segment must keep the ring phase");
-    if (INIT == SEG_BIAS || INIT == SEG_BIAS_SCALED) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(ws.bias + n * SW_BIAS_TILE_FLOATS + 4 * g);
-                if (INIT == SEG_BIAS_SCALED) {
-                    out[n][4 * g + 0] = b[0] * scale; out[n][4 * g + 1] = b[1] * scale;
-                    out[n][4 * g + 2] = b[2] * scale; out[n][4 * g + 3] = b[3] * scale;
-                } else {
-                    out[n][4 * g + 0] = b[0]; out[n][4 * g + 1] = b[1];
-                    out[n][4 * g + 2] = b[2]; out[n][4 * g + 3] = b[3];
-                }
-            }
-        }
-        ws.bias += NT * SW_BIAS_TILE_FLOATS;
-    } else if (INIT == SEG_ZERO) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[n][r] = 0.f;
-    }
-    seg_steps<0, NS, NT, KT>(out, kin, ws);
+    f32x16 binit;
+    seg_init_read<INIT>(binit, ws, 0);
+    seg_steps<0, NS, NT, KT, INIT>(out, kin, ws, binit, scale);
+    if (INIT == SEG_BIAS || INIT == SEG_BIAS_SCALED) ws.bias += NT * SW_BIAS_TILE_FLOATS;
     ws.base += NS * 1024;
 }
 
@@ -184,6 +191,11 @@ __device__ __forceinline__ void head_valu(const f32x16 (&x)[NT], WStream& ws, fl
                 acc = fmaf(w[2], x[n][4 * g + 2], acc); acc = fmaf(w[3], x[n][4 * g + 3], acc);
             }
         res[o] = acc + __shfl_xor(acc, 32, 64);
+        // Pin the finished sum HERE (volatile asm keeps its order with the DMA statements of the next
+        // segment).  Unpinned, the scheduler sinks half of the sigma dot product below the whole FEAT/VIEWS
+        // tail - sigma is only consumed by the compositing - and keeps 64 weights plus the layer-7
+        // activations alive across it, which is what spilled the per-ray state of the render kernel.
+        asm volatile("" : "+v"(res[o]));
     }
     ws.bias += NOUT * NT * SW_BIAS_TILE_FLOATS;
 }
