@@ -61,11 +61,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SWNERF_BENCH_REHEARSAL=1: run the N>1 control flow on a box with fewer GPUs than ranks (ranks share
+    # cards, gloo instead of RCCL, pixels staged through the host for the gather).  Not a measurement.
+    rehearsal = os.environ.get("SWNERF_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -108,6 +115,8 @@ def main():
     def step():
         rgb, disp, acc, _ = render.render(HW, HW, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kw)
         px = torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+        if world > 1 and rehearsal:
+            return parallel.gather_pixels(px.cpu()).to(dev)
         return parallel.gather_pixels(px) if world > 1 else px
 
     def fence():
@@ -128,7 +137,7 @@ def main():
         dt = time.perf_counter() - t0
         hook.on = False
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.shape == (world * N_RAND, 5) and bool(torch.isfinite(out[:, :3]).all())
@@ -148,7 +157,8 @@ def main():
     result = {
         "metric": "rays/sec (64+128 samples/ray)", "value": world * N_RAND * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo; not a measurement)" if rehearsal else ""),
         "config": {"workload": "C2: lego-like 800x800 camera, N_rand=4096 rays/GPU/step, 64 coarse + 128 fine samples, "
                                "coarse+fine 8x256 nets (use_viewdirs), white_bkgd, perturb=0; render() forward "
                                "(get rays resident -> ray batch -> coarse pass -> resample -> fine pass)"
