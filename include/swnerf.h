@@ -135,6 +135,36 @@ int swnerf_mlp_backward_dx(const float* packed_bwd, const float* act, const floa
 int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
                    float* C, int ldc, float* bias, void* stream);
 
+/* ---- training path of DirectTemporalNeRF (autograd of model.py:128-151; the loss of
+ * d_nerf/run_dnerf.py:690-725 needs d/d(position_delta) too).  The forward is the composition the
+ * reference runs: deformation net -> dx; gamma(x + dx) (swnerf_embed); canonical net
+ * (swnerf_mlp_forward_train on [gamma(x+dx), gamma(d)]).  Backward: canonical dX chain that also returns
+ * the gradient w.r.t. the re-embedded positions (through the sin/cos of gamma), then the deformation dX chain
+ * seeded with d dx = d pts + d position_delta.
+ * Backward stream kinds for swnerf_packed_bwd_floats_kind / swnerf_pack_net_bwd_kind:
+ *   SWNERF_BWD_CANON            what swnerf_pack_net_bwd writes (params: the 24 canonical tensors)
+ *   SWNERF_BWD_CANON_INPUT_GRAD the same plus the position-embedding columns of pts_linears.0/.5
+ *   SWNERF_BWD_DEFORM           `_time.1..7` trunk columns + `_time_out.weight` (params: the 18 tensors
+ *                               _time.0.weight, _time.0.bias, ..., _time_out.weight, _time_out.bias)
+ * deform_forward_train: packed = a SWNERF_NET_DNERF blob; x [M,C] as for swnerf_mlp_forward, t_emb [M,1+2*L_time];
+ *   writes dx [M,3] and act_d [M, swnerf_act_floats_per_row()] (h_l of `_time` at column 256*l).
+ * backward_dx_pts: as swnerf_mlp_backward_dx with a SWNERF_BWD_CANON_INPUT_GRAD stream; pts [M,3] = the
+ *   positions that were embedded (x + dx); also writes d_pts [M,3].
+ * deform_backward_dx: d_dx [M,3] -> grad_d [M, same layout as act_d] = d(pre-activation) of `_time.l`. */
+#define SWNERF_BWD_CANON 0
+#define SWNERF_BWD_CANON_INPUT_GRAD 1
+#define SWNERF_BWD_DEFORM 2
+size_t swnerf_packed_bwd_floats_kind(int bwd_kind);
+int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
+                             float* packed_bwd, void* stream);
+int swnerf_deform_forward_train(const float* packed, const float* x, const float* t_emb, int64_t M,
+                                int L_pos, int L_dir, int L_time, float* dx /*[M,3]*/, float* act_d, void* stream);
+int swnerf_mlp_backward_dx_pts(const float* packed_bwd, const float* act, const float* d_out /*[M,4]*/,
+                               const float* pts /*[M,3]*/, int64_t M, int L_pos,
+                               float* grad, float* d_pts /*[M,3]*/, void* stream);
+int swnerf_deform_backward_dx(const float* packed_bwd, const float* act_d, const float* d_dx /*[M,3]*/, int64_t M,
+                              float* grad_d, void* stream);
+
 /* network_query_fn on bare points (nerf/load_model.py:56-74; nerf/extract_mesh.py:27-90, :155-175):
  * pts [M,3] world positions, packed = a SWNERF_NET_CANON blob; the positional encodings are
  * evaluated in registers.  shared_dirs == 0: dirs [M,3], one direction per point -> out [M,4] = raw

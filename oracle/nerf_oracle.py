@@ -119,9 +119,11 @@ def nerf_mlp(sd, x, input_ch=63, input_ch_views=27, prefix=""):
     return torch.cat([rgb, sigma], -1)
 
 
-def dnerf_mlp(sd, x, t_emb, multires=10, input_ch=63, input_ch_views=27, zero_canonical=True):
+def dnerf_mlp(sd, x, t_emb, multires=10, input_ch=63, input_ch_views=27, zero_canonical=True, dx_value=None):
     """DirectTemporalNeRF.forward (model.py:138-151) + query_time (model.py:128-136).
-    t_emb: [M, 21] embedded frame time (all rows the same time).  Returns (out[M,4], dx[M,3])."""
+    t_emb: [M, 21] embedded frame time (all rows the same time).  Returns (out[M,4], dx[M,3]).
+    dx_value (tests only): substitute these VALUES for dx before the re-embedding, gradients untouched - the top
+    band of gamma() multiplies a 1e-7 difference in dx by 512, so gradient parity is checked at equal dx."""
     pts, views = torch.split(x, [input_ch, input_ch_views], dim=-1)
     cur_time = float(t_emb[0, 0])
     if cur_time == 0. and zero_canonical:
@@ -133,6 +135,8 @@ def dnerf_mlp(sd, x, t_emb, multires=10, input_ch=63, input_ch_views=27, zero_ca
             if i == 4:
                 h = torch.cat([pts, h], -1)
         dx = _lin(sd, "_time_out", h)
+        if dx_value is not None:
+            dx = dx + (dx_value - dx).detach()
         pts = embed(pts[:, :3] + dx, multires)
     out = nerf_mlp(sd, torch.cat([pts, views], -1), input_ch, input_ch_views, prefix="_occ.")
     return out, dx

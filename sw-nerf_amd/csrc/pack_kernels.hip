@@ -27,6 +27,10 @@ struct PackSeg {
     // transpose != 0 (backward stream): the GEMM's output rows are W's COLUMNS row0.. (out_dim of them) and
     // its k index runs over W's ROWS (kvalid of them): value = W[kbase + col][row0 + row]
     int transpose, row0, kvalid;
+    // rowmap != 0 (transposed only): output row (n, i) is the position-embedding SLOT the lane holding it
+    // filled in the forward pass - W column row0 + sw_pos_col(16n + r, h) with frow(r,h) == i - so the dX chain
+    // leaves d gamma(x) in the registers pe_pos() wrote gamma(x) to.
+    int rowmap;
 };
 
 __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
@@ -51,7 +55,12 @@ __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
             if (row < s.out_dim && col >= 0) v = s.W[(size_t)row * s.in_dim + s.kbase[kt] + col];
         } else {
             const int k = s.kbase[kt] + col;
-            if (row < s.out_dim && k < s.kvalid) v = s.W[(size_t)k * s.in_dim + s.row0 + row];
+            int wcol = row;
+            if (s.rowmap) {
+                const int hh = (i >> 2) & 1, rr = (i & 3) + 4 * (i >> 3);      // inverse of sw_frow
+                wcol = sw_pos_col(16 * n + rr, hh, s.Lp);
+            }
+            if (wcol >= 0 && wcol < s.out_dim && k < s.kvalid) v = s.W[(size_t)k * s.in_dim + s.row0 + wcol];
         }
         s.dstW[e] = v;
     }
@@ -79,17 +88,17 @@ struct Packer {
         s.W = W; s.b = bias; s.out_dim = out_dim; s.in_dim = in_dim; s.NT = NT; s.KT = KT;
         for (int i = 0; i < 10; ++i) { s.ktype[i] = i < KT ? kt[i] : 0; s.kbase[i] = i < KT ? kb[i] : 0; }
         s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
-        s.transpose = 0; s.row0 = 0; s.kvalid = 0;
+        s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
         launch(s, NT, KT, bias != nullptr);
     }
     // transposed segment of the backward stream: out rows = W columns [row0, row0+n_out), k = W rows [0, kvalid)
-    void segT(const float* W, int w_rows, int w_cols, int row0, int n_out, int NT, int KT) {
+    void segT(const float* W, int w_rows, int w_cols, int row0, int n_out, int NT, int KT, int rowmap = 0) {
         if (rc) return;
         PackSeg s;
         s.W = W; s.b = nullptr; s.out_dim = n_out; s.in_dim = w_cols; s.NT = NT; s.KT = KT;
         for (int i = 0; i < 10; ++i) { s.ktype[i] = KT_TRUNK; s.kbase[i] = 32 * i; }
         s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
-        s.transpose = 1; s.row0 = row0; s.kvalid = w_rows;
+        s.transpose = 1; s.row0 = row0; s.kvalid = w_rows; s.rowmap = rowmap;
         launch(s, NT, KT, false);
     }
     void launch(PackSeg& s, int NT, int KT, bool has_bias) {
@@ -105,7 +114,7 @@ struct Packer {
             PackSeg s;
             s.W = W; s.b = W + (size_t)o * in_dim; s.out_dim = in_dim; s.in_dim = in_dim; s.NT = in_dim / 32; s.KT = 0;
             for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
-            s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0;
+            s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
             hipLaunchKernelGGL(pack_seg_kernel, dim3((s.NT * SW_BIAS_TILE_FLOATS + 255) / 256), dim3(256), 0, st, s);
             rc = sw_check(hipGetLastError(), "pack_net launch");
             b += s.NT * SW_BIAS_TILE_FLOATS;
@@ -190,29 +199,57 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     return tail(vl.w, packed + SW_CANON_VL_OFFSET);
 }
 
-// The backward (dX chain) stream of a canonical net: transposed weights in the order
-// mlp_backward_dx_kernel consumes them (swnerf_common.h SW_BWD_*), then alpha_linear.weight as 8 bias tiles.
-extern "C" int swnerf_pack_net_bwd(const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
+// The backward (dX chain) streams: transposed weights in the order the backward kernels consume them
+// (swnerf_common.h SW_BWD_* / SW_DBWD_*), then the head weights as bias-style tiles.
+extern "C" size_t swnerf_packed_bwd_floats_kind(int bwd_kind) {
+    switch (bwd_kind) {
+        case SWNERF_BWD_CANON: return (size_t)SW_BWD_FLOATS;
+        case SWNERF_BWD_CANON_INPUT_GRAD: return (size_t)SW_BWD_IG_FLOATS;
+        case SWNERF_BWD_DEFORM: return (size_t)SW_DBWD_FLOATS;
+    }
+    return 0;
+}
+
+extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
     if (!params || !packed_bwd) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: NULL pointer");
+    if (bwd_kind != SWNERF_BWD_CANON && bwd_kind != SWNERF_BWD_CANON_INPUT_GRAD && bwd_kind != SWNERF_BWD_DEFORM)
+        return sw_fail(SWNERF_E_ARG, "pack_net_bwd: unknown stream kind %d", bwd_kind);
     if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "pack_net_bwd: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
-    for (int i = 0; i < 24; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: params[%d] is NULL", i);
+    const int np = bwd_kind == SWNERF_BWD_DEFORM ? 18 : 24;
+    for (int i = 0; i < np; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: params[%d] is NULL", i);
     const int Cpos = 3 * (1 + 2 * L_pos), Cdir = 3 * (1 + 2 * L_dir);
     hipStream_t st = (hipStream_t)stream;
-    Packer pk{st, packed_bwd, packed_bwd + SW_BWD_W_FLOATS, L_pos, L_dir, 0, 0};
+    auto tail = [&](Packer& pk, size_t steps) {
+        if (pk.rc) return pk.rc;
+        if (pk.w != packed_bwd + steps * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: internal layout mismatch");
+        return sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
+    };
+    if (bwd_kind == SWNERF_BWD_DEFORM) {
+        Packer pk{st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, L_dir, 0, 0};
+        for (int l = 7; l >= 1; --l)                                  // _time.l.weight[:, -256:]^T
+            pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
+        int rc = tail(pk, SW_DBWD_STEPS);
+        if (rc) return rc;
+        pk.vecs(params[16], 3, 256);                                  // _time_out.weight rows, tile n: [h][r] = w[o][32n + frow(r,h)]
+        return pk.rc;
+    }
+    const bool ig = bwd_kind == SWNERF_BWD_CANON_INPUT_GRAD;
+    const size_t wfloats = ig ? SW_BWD_IG_W_FLOATS : SW_BWD_W_FLOATS;
+    Packer pk{st, packed_bwd, packed_bwd + wfloats, L_pos, L_dir, 0, 0};
     pk.segT(params[22], 3, 128, 0, 128, 4, 1);                       // rgb_linear.weight [3,128]^T
     pk.segT(params[16], 128, 256 + Cdir, 0, 256, 8, 4);              // views_linears.0.weight[:, :256]^T
     pk.segT(params[18], 256, 256, 0, 256, 8, 8);                     // feature_linear.weight^T
-    for (int l = 7; l >= 1; --l)                                      // pts_linears.l.weight[:, -256:]^T
+    for (int l = 7; l >= 1; --l) {                                   // pts_linears.l.weight[:, -256:]^T
+        if (ig && l == 5) pk.segT(params[10], 256, Cpos + 256, 0, Cpos, 2, 8, 1);   // ... [:, :Cpos]^T -> d gamma(x)
         pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
-    if (pk.rc) return pk.rc;
-    if (pk.w != packed_bwd + (size_t)SW_BWD_STEPS * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: internal layout mismatch");
-    int rc = sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
+    }
+    if (ig) pk.segT(params[0], 256, Cpos, 0, Cpos, 2, 8, 1);         // pts_linears.0.weight^T -> d gamma(x)
+    int rc = tail(pk, ig ? SW_BWD_IG_STEPS : SW_BWD_STEPS);
     if (rc) return rc;
-    // alpha_linear.weight [1,256] laid out like a bias vector: tile n, [h][r] = w[32n + frow(r,h)]
-    PackSeg s;
-    s.W = params[20]; s.b = params[20]; s.out_dim = 256; s.in_dim = 256; s.NT = 8; s.KT = 0;
-    for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
-    s.Lp = s.Ld = s.Lt = 0; s.dstW = packed_bwd; s.dstB = packed_bwd + SW_BWD_W_FLOATS; s.transpose = 0; s.row0 = 0; s.kvalid = 0;
-    hipLaunchKernelGGL(pack_seg_kernel, dim3(1), dim3(256), 0, st, s);
-    return sw_check(hipGetLastError(), "pack_net_bwd launch");
+    pk.vecs(params[20], 1, 256);                                     // alpha_linear.weight [1,256] as 8 bias-style tiles
+    return pk.rc;
+}
+
+extern "C" int swnerf_pack_net_bwd(const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
+    return swnerf_pack_net_bwd_kind(SWNERF_BWD_CANON, params, L_pos, L_dir, packed_bwd, stream);
 }

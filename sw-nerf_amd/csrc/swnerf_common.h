@@ -62,6 +62,16 @@
 #define SW_BWD_W_FLOATS ((SW_BWD_STEPS + SW_RING) * SW_STEP_FLOATS)
 #define SW_BWD_BIAS_TILES 8
 #define SW_BWD_FLOATS (SW_BWD_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// ... with the gradient w.r.t. the embedded positions (D-NeRF training: it flows on into the deformation net):
+// RGB^T | VIEWS^T | FEAT^T | L7^T L6^T | L5[:, :Cpos]^T (2x8) | L5[:, Cpos:]^T | L4^T .. L1^T | L0^T (2x8)
+#define SW_BWD_IG_STEPS (SW_BWD_STEPS + 2 * 64)
+#define SW_BWD_IG_W_FLOATS ((SW_BWD_IG_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_BWD_IG_FLOATS (SW_BWD_IG_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// deformation net (`_time`): L7^T .. L1^T (trunk columns); then _time_out.weight [3,256] as 3 x 8 bias tiles
+#define SW_DBWD_STEPS (7 * 256)
+#define SW_DBWD_W_FLOATS ((SW_DBWD_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_DBWD_BIAS_TILES 24
+#define SW_DBWD_FLOATS (SW_DBWD_W_FLOATS + SW_DBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
 // C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile
 SW_HD int sw_frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -45,6 +45,29 @@ class _NoBackward(torch.autograd.Function):
             "run the render path under torch.no_grad()")
 
 
+def _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias):
+    """C[:, c_col:c_col+Ni] += A[:, a_col:a_col+No]^T . B[:, b_col:b_col+Ni];  bias += column sums of that A block"""
+    _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
+                                C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(bias), st), "gemm_tn")
+
+
+def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
+    """dW / db of the 12 Linear layers of the canonical net (g: zeroed fp32 tensors in _CANON_ORDER) from the
+    dX chain's `grad`, the saved `act`, the embedded inputs x = [gamma(x) | gamma(d)] and d raw."""
+    mm = lambda A, a_col, No, B, b_col, Ni, wi, c_col, with_bias: _gemm_tn(
+        L, st, M, A, a_col, No, B, b_col, Ni, g[wi], c_col, g[wi + 1] if with_bias else None)
+    mm(grad, 0, 256, x, 0, Cpos, 0, 0, True)                                   # pts_linears.0
+    for l in (1, 2, 3, 4, 6, 7):
+        mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, 2 * l, 0, True)
+    mm(grad, 1280, 256, x, 0, Cpos, 10, 0, True)                               # pts_linears.5 = [pts | h4]
+    mm(grad, 1280, 256, act, 1024, 256, 10, Cpos, False)
+    mm(grad, 2304, 128, act, 2048, 256, 16, 0, True)                           # views_linears.0 = [feature | dirs]
+    mm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
+    mm(grad, 2048, 256, act, 1792, 256, 18, 0, True)                           # feature_linear
+    mm(d_out, 3, 1, act, 1792, 256, 20, 0, True)                               # alpha_linear
+    mm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
+
+
 class _MlpTrain(torch.autograd.Function):
     """Differentiable forward of the static 8x256 net: the forward kernel saves
     every layer's activation; backward = the register-resident dX chain over the transposed weight
@@ -78,25 +101,77 @@ class _MlpTrain(torch.autograd.Function):
         _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(act), _lib.ptr(d_out), M, _lib.ptr(grad), st),
                    "mlp_backward_dx")
         g = [torch.zeros_like(p, dtype=torch.float32) for p in params]      # order: _CANON_ORDER
-        Cpos, Cdir = module.input_ch, module.input_ch_views
-
-        def gemm(A, a_col, No, B, b_col, Ni, wi, c_col, with_bias):
-            C = g[wi]
-            _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
-                                        C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(g[wi + 1]) if with_bias else None, st),
-                       "gemm_tn")
-
-        gemm(grad, 0, 256, x, 0, Cpos, 0, 0, True)                                   # pts_linears.0
-        for l in (1, 2, 3, 4, 6, 7):
-            gemm(grad, 256 * l, 256, act, 256 * (l - 1), 256, 2 * l, 0, True)
-        gemm(grad, 1280, 256, x, 0, Cpos, 10, 0, True)                               # pts_linears.5 = [pts | h4]
-        gemm(grad, 1280, 256, act, 1024, 256, 10, Cpos, False)
-        gemm(grad, 2304, 128, act, 2048, 256, 16, 0, True)                           # views_linears.0 = [feature | dirs]
-        gemm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
-        gemm(grad, 2048, 256, act, 1792, 256, 18, 0, True)                           # feature_linear
-        gemm(d_out, 3, 1, act, 1792, 256, 20, 0, True)                               # alpha_linear
-        gemm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
+        _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g)
         return (None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
+
+
+class _DnerfTrain(torch.autograd.Function):
+    """Differentiable DirectTemporalNeRF.forward for t != 0 (model.py:128-151): returns (out, dx), both with
+    gradients - d_nerf/run_dnerf.py:690-725 puts a TV loss on dx (`position_delta`) next to the image loss.
+    Forward = deformation net (activations saved) -> gamma(x + dx) -> canonical net (activations saved).
+    Backward = canonical dX chain incl. d gamma(x+dx) -> d(x+dx) through the sin/cos Jacobian, the deformation
+    dX chain seeded with d dx = d(x+dx) + d position_delta, then one TN GEMM per Linear layer of both nets.
+    params: the 24 `_occ` tensors (_CANON_ORDER) then the 18 `_time`/`_time_out` tensors (_DEFORM_ORDER)."""
+
+    @staticmethod
+    def forward(ctx, module, x, t_emb, *params):
+        kind, packed, Lp, Ld, Lt = module.packed()
+        occ = module._occ
+        L = _lib.lib()
+        M = x.shape[0]
+        st = _lib.stream_of(x)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        nact = L.swnerf_act_floats_per_row()
+        dx, act_d = new(M, 3), new(M, nact)
+        _lib.check(L.swnerf_deform_forward_train(_lib.ptr(packed), _lib.ptr(x), _lib.ptr(t_emb), M, Lp, Ld, Lt,
+                                                 _lib.ptr(dx), _lib.ptr(act_d), st), "deform_forward_train")
+        Cpos = module.input_ch
+        pts2 = x[:, :3] + dx                                                     # model.py:147
+        x2 = new(M, x.shape[1])
+        x2[:, Cpos:] = x[:, Cpos:]
+        emb = new(M, Cpos)
+        _lib.check(L.swnerf_embed(_lib.ptr(pts2), M, 3, Lp, _lib.ptr(emb), st), "embed")   # model.py:148-149
+        x2[:, :Cpos] = emb
+        out, act_c = new(M, 4), new(M, nact)
+        _lib.check(L.swnerf_mlp_forward_train(_lib.ptr(occ.packed()[1]), _lib.ptr(x2), M, Lp, Ld, _lib.ptr(out), _lib.ptr(act_c), st),
+                   "mlp_forward_train")
+        ctx.module = module
+        ctx.save_for_backward(x, t_emb, x2, pts2, act_d, act_c, *params)
+        return out, dx
+
+    @staticmethod
+    def backward(ctx, d_out, d_dx):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise NotImplementedError("swnerf: gradients w.r.t. the embedded inputs are not built (rays are data in train())")
+        x, t_emb, x2, pts2, act_d, act_c, *params = ctx.saved_tensors
+        module = ctx.module
+        occ = module._occ
+        L = _lib.lib()
+        M = x.shape[0]
+        st = _lib.stream_of(x)
+        kind, names, Lp, Ld, Lt = module._pack_params()
+        Cpos, Cdir, Ct = module.input_ch, module.input_ch_views, module.input_ch_time
+        d_out = (torch.zeros((M, 4), dtype=torch.float32, device=x.device) if d_out is None else d_out.contiguous().float())
+        grad_c, d_pts = torch.empty_like(act_c), torch.empty((M, 3), dtype=torch.float32, device=x.device)
+        _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(act_c), _lib.ptr(d_out),
+                                                _lib.ptr(pts2), M, Lp, _lib.ptr(grad_c), _lib.ptr(d_pts), st), "mlp_backward_dx_pts")
+        g = [torch.zeros_like(p, dtype=torch.float32) for p in params]
+        _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g[:24])
+        g_dx = d_pts if d_dx is None else (d_pts + d_dx.float()).contiguous()
+        grad_d = torch.empty_like(act_d)
+        _lib.check(L.swnerf_deform_backward_dx(_lib.ptr(module.packed_bwd(_lib.BWD_DEFORM)), _lib.ptr(act_d), _lib.ptr(g_dx), M,
+                                               _lib.ptr(grad_d), st), "deform_backward_dx")
+        gd = g[24:]
+        mm = lambda A, a_col, No, B, b_col, Ni, wi, c_col, with_bias: _gemm_tn(
+            L, st, M, A, a_col, No, B, b_col, Ni, gd[wi], c_col, gd[wi + 1] if with_bias else None)
+        mm(grad_d, 0, 256, x, 0, Cpos, 0, 0, True)                               # _time.0 = [gamma(x) | gamma(t)]
+        mm(grad_d, 0, 256, t_emb, 0, Ct, 0, Cpos, False)
+        for l in (1, 2, 3, 4, 6, 7):
+            mm(grad_d, 256 * l, 256, act_d, 256 * (l - 1), 256, 2 * l, 0, True)
+        mm(grad_d, 1280, 256, x, 0, Cpos, 10, 0, True)                           # _time.5 = [gamma(x) | h4]
+        mm(grad_d, 1280, 256, act_d, 1024, 256, 10, Cpos, False)
+        mm(g_dx, 0, 3, act_d, 1792, 256, 16, 0, True)                            # _time_out
+        return (None, None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
 def _tag_no_backward(out, module):
@@ -112,23 +187,22 @@ class _PackedMixin:
     def _init_pack(self):
         self._pack_key = None
         self._packed = None
-        self._pack_bwd_key = None
-        self._packed_bwd = None
+        self._pack_bwd = {}
 
-    def packed_bwd(self):
-        """The transposed weight stream of the backward dX chain (static nets), cached like packed()."""
+    def packed_bwd(self, bwd_kind=0):
+        """A transposed weight stream of the backward dX chains (include/swnerf.h SWNERF_BWD_*), cached like packed()."""
         kind, names, Lp, Ld, Lt = self._pack_params()
         sd = dict(self.named_parameters())
-        ps = [sd[n] for n in names[:24]]
+        ps = [sd[n] for n in (_DEFORM_ORDER if bwd_kind == _lib.BWD_DEFORM else names[:24])]
         key = tuple((p.data_ptr(), p._version) for p in ps)
-        if key != self._pack_bwd_key:
+        if self._pack_bwd.get(bwd_kind, (None, None))[0] != key:
             L = _lib.lib()
             ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
-            arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in ps32])
-            buf = torch.empty(L.swnerf_packed_bwd_floats(), dtype=torch.float32, device=ps[0].device)
-            _lib.check(L.swnerf_pack_net_bwd(arr, Lp, Ld, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_bwd")
-            self._packed_bwd, self._pack_bwd_key = buf, key
-        return self._packed_bwd
+            arr = (ctypes.c_void_p * len(ps32))(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_bwd_floats_kind(bwd_kind), dtype=torch.float32, device=ps[0].device)
+            _lib.check(L.swnerf_pack_net_bwd_kind(bwd_kind, arr, Lp, Ld, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_bwd")
+            self._pack_bwd[bwd_kind] = (key, buf)
+        return self._pack_bwd[bwd_kind][1]
 
     def _wants_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
@@ -292,6 +366,21 @@ class DirectTemporalNeRF(nn.Module, _PackedMixin):
         lo, hi = float(lo), float(hi)
         assert lo == hi, "Only accepts all points from same time"
         run_deform = not (lo == 0. and self.zero_canonical)
+        if self._wants_grad():
+            if not run_deform:                                                  # model.py:143-145: canonical net only, dx = 0
+                out, dx = self._occ(x, ts)
+                return out, dx
+            kind, names, Lp, Ld, Lt = self._pack_params()
+            x = _lib.dev_f32(x, "x", self.input_ch + self.input_ch_views)
+            lead = x.shape[:-1]
+            flat = x.reshape(-1, x.shape[-1])
+            te = _lib.dev_f32(t, "ts[0]", 1 + 2 * Lt).reshape(-1, 1 + 2 * Lt)
+            if flat.shape[0] == 0:
+                return (torch.empty((*lead, 4), dtype=torch.float32, device=x.device),
+                        torch.empty((*lead, 3), dtype=torch.float32, device=x.device))
+            sd = dict(self.named_parameters())
+            out, dx = _DnerfTrain.apply(self, flat, te, *[sd[n] for n in names])
+            return out.reshape(*lead, 4), dx.reshape(*lead, 3)
         out, dx = self._forward_hip(x, t_emb=t, run_deform=run_deform, want_dx=True)
         return out, dx
 

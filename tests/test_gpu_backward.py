@@ -150,3 +150,65 @@ def test_training_step_matches_autograd(dev):
     with torch.no_grad():
         after = q(pts.to(dev)[:4], rb[:4, -3:].to(dev), net_f)
     assert float((after - before).abs().max()) > 1e-5
+
+
+def _dnerf_net(dev, sd_np):
+    import swnerf.embedder as embedder, swnerf.model as model
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    m = model.DirectTemporalNeRF(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=5, skips=[4],
+                                 use_viewdirs=True, embed_fn=embed_fn, zero_canonical=True)
+    m.load_state_dict({k: T(v) for k, v in sd_np.items()})
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("M", [300, 32, 1])
+def test_dnerf_mlp_backward_matches_autograd(dev, M):
+    """DirectTemporalNeRF.forward at t != 0 with gradients on BOTH outputs (out and dx = position_delta, the TV-loss
+    operand of d_nerf/run_dnerf.py:690-725): every parameter gradient of `_time`, `_time_out` and `_occ`."""
+    sd_np = cases.weights_dnerf()
+    x = T(cases.g4_inputs()["x"][:M])
+    t_emb = O.embed(torch.full((M, 1), 0.5), 10)
+    rng = np.random.default_rng(19)
+    G, Gdx = T(rng.standard_normal((M, 4)).astype(np.float32)), T(rng.standard_normal((M, 3)).astype(np.float32))
+    net = _dnerf_net(dev, sd_np)
+    out, dx = net(x.to(dev), [t_emb.to(dev), t_emb.to(dev)])
+    assert out.requires_grad and dx.requires_grad and out.shape == (M, 4) and dx.shape == (M, 3)
+    ((out * G.to(dev)).sum() + (dx * Gdx.to(dev)).sum()).backward()
+    # forward values: the same as the inference kernel's
+    with torch.no_grad():
+        out_i, dx_i = net(x.to(dev), [t_emb.to(dev), t_emb.to(dev)])
+    relclose(dx, dx_i, rtol=1e-5, atol=1e-6, what="dx train vs inference")
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
+    o_ref, dx_ref = O.dnerf_mlp(sd, x, t_emb, dx_value=dx.detach().cpu())
+    relclose(dx, dx_ref, rtol=1e-5, atol=2e-6, what="dx")
+    relclose(out, o_ref, rtol=2e-4, atol=2e-5, what="out at equal dx")
+    ((o_ref * G).sum() + (dx_ref * Gdx).sum()).backward()
+    _grad_check({k: p.grad for k, p in net.named_parameters()}, {k: v.grad for k, v in sd.items()}, f"dnerf M={M}", rtol=3e-4)
+    # only the TV-style gradient (d out = None inside autograd): `_occ` gets exactly zero, `_time` the direct path
+    net.zero_grad()
+    out, dx = net(x.to(dev), [t_emb.to(dev), t_emb.to(dev)])
+    (dx * Gdx.to(dev)).sum().backward()
+    for v in sd.values():
+        v.grad = None
+    (O.dnerf_mlp(sd, x, t_emb)[1] * Gdx).sum().backward()
+    ours = {k: p.grad for k, p in net.named_parameters() if k.startswith("_time")}
+    _grad_check(ours, {k: sd[k].grad for k in ours}, "dx-only", rtol=3e-4)
+    assert all(float(p.grad.abs().max()) == 0.0 for k, p in net.named_parameters() if k.startswith("_occ"))
+
+
+def test_dnerf_zero_time_trains_canonical_only(dev):
+    """t == 0 with zero_canonical (model.py:143-145): dx = 0, only `_occ` receives gradients."""
+    sd_np = cases.weights_dnerf()
+    M = 100
+    x = T(cases.g4_inputs()["x"][:M])
+    t_emb = O.embed(torch.zeros((M, 1)), 10)
+    G = T(np.random.default_rng(23).standard_normal((M, 4)).astype(np.float32))
+    net = _dnerf_net(dev, sd_np)
+    out, dx = net(x.to(dev), [t_emb.to(dev), t_emb.to(dev)])
+    assert float(dx.abs().max()) == 0.0
+    (out * G.to(dev)).sum().backward()
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
+    (O.dnerf_mlp(sd, x, t_emb)[0] * G).sum().backward()
+    ours = {k: p.grad for k, p in net.named_parameters() if k.startswith("_occ")}
+    _grad_check(ours, {k: sd[k].grad for k in ours}, "t=0")
+    assert all(p.grad is None for k, p in net.named_parameters() if k.startswith("_time"))
