@@ -212,3 +212,46 @@ def test_dnerf_zero_time_trains_canonical_only(dev):
     ours = {k: p.grad for k, p in net.named_parameters() if k.startswith("_occ")}
     _grad_check(ours, {k: sd[k].grad for k in ours}, "t=0")
     assert all(p.grad is None for k, p in net.named_parameters() if k.startswith("_time"))
+
+
+def test_dnerf_training_step_with_tv_loss(dev):
+    """The D-NeRF training loss (d_nerf/run_dnerf.py:690-725): image loss at the frame's time plus the TV term between
+    position_delta at two times on the SAME depths (`z_vals=extras['z_vals'].detach()`), through render_rays on the
+    differentiable op path.  Compared with autograd through the CPU oracle; the tolerance is set by gamma()'s top
+    band, which turns the oracle's 1e-7 difference in dx into ~5e-5 in the re-embedded features."""
+    import swnerf.embedder as embedder, swnerf.render_dnerf as rd
+    sd_np = cases.weights_dnerf()
+    g = cases.g8_inputs(n=40)
+    rb = lambda t: O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6., frame_time=t)
+    target = T(np.random.default_rng(5).uniform(0, 1, (40, 3)).astype(np.float32))
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = embedder.get_embedder(4, 3, 0)
+    embedtime_fn, _ = embedder.get_embedder(10, 1, 0)
+    q = lambda inputs, viewdirs, ts, network_fn: rd.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn, netchunk=1024)
+    img2mse = lambda x, y: torch.mean((x - y) ** 2)
+    tv_w = 0.1
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
+    r1 = O.render_rays_dnerf(rb(0.5), sd, 64, white_bkgd=True)
+    r0 = O.render_rays_dnerf(rb(0.45), sd, 64, white_bkgd=True)
+    (img2mse(r1["rgb_map"], target) + tv_w * (r1["position_delta"] - r0["position_delta"]).pow(2).sum()).backward()
+
+    net = _dnerf_net(dev, sd_np)
+    e1 = rd.render_rays(rb(0.5).to(dev), net, q, 64, retraw=True, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    e0 = rd.render_rays(rb(0.45).to(dev), net, q, 64, retraw=True, white_bkgd=True, z_vals=e1["z_vals"].detach())
+    assert e1["position_delta"].requires_grad and e1["rgb_map"].requires_grad
+    loss = img2mse(e1["rgb_map"], target.to(dev)) + tv_w * (e1["position_delta"] - e0["position_delta"]).pow(2).sum()
+    loss.backward()
+    relclose(e1["position_delta"], r1["position_delta"], rtol=1e-5, atol=2e-6, what="position_delta")
+    _grad_check({k: p.grad for k, p in net.named_parameters()}, {k: v.grad for k, v in sd.items()}, "dnerf step", rtol=5e-3)
+    # the default D-NeRF configuration (64+128, one net): runs, every parameter gets a finite gradient, Adam moves the render
+    net.zero_grad()
+    e = rd.render_rays(rb(0.5).to(dev), net, q, 64, N_importance=128, retraw=True, white_bkgd=True)
+    (img2mse(e["rgb_map"], target.to(dev)) + tv_w * e["position_delta"].pow(2).sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    opt.step()
+    with torch.no_grad():
+        after = rd.render_rays(rb(0.5).to(dev), net, q, 64, N_importance=128, white_bkgd=True)["rgb_map"]
+    assert float((after - e["rgb_map"].detach()).abs().max()) > 1e-6
