@@ -66,10 +66,12 @@ def closure_embedders(network_query_fn):
     if tagged is not None:
         return dict(tagged)
     try:
-        nl = inspect.getclosurevars(network_query_fn).nonlocals
+        cv = inspect.getclosurevars(network_query_fn)
     except TypeError:
         return {}
-    return {k: nl[k] for k in ("embed_fn", "embeddirs_fn", "embedtime_fn") if k in nl}
+    # create_nerf's lambda closes over locals; a script that builds the same lambda at module level refers to globals
+    names = {**cv.globals, **cv.nonlocals}
+    return {k: names[k] for k in ("embed_fn", "embeddirs_fn", "embedtime_fn") if k in names}
 
 
 def fused_plan(network_query_fn, nets, need_time=False):

@@ -118,6 +118,26 @@ def test_fused_dispatch_detection(built):
         assert render.fused_plan(tagged, [net]) == (10, 4, 0)
 
 
+_g_e10 = _g_e4 = None
+# a query lambda written at MODULE level (scripts, notebooks): its encoders are globals, not closure cells
+_g_query = lambda inputs, viewdirs, network_fn: None if False else (embed_fn, embeddirs_fn)     # noqa: E731,F821
+
+
+def test_fused_dispatch_sees_module_level_lambda(built):
+    from swnerf import embedder, model, render
+    e10, c10 = embedder.get_embedder(10, 3, 0)
+    e4, c4 = embedder.get_embedder(4, 3, 0)
+    net = model.vallina_NeRF(D=8, W=256, input_ch=c10, input_ch_views=c4, output_ch=5, skips=[4], use_viewdirs=True)
+    g = globals()
+    g["embed_fn"], g["embeddirs_fn"] = e10, e4
+    try:
+        with torch.no_grad():
+            assert render.closure_embedders(_g_query) == {"embed_fn": e10, "embeddirs_fn": e4}
+            assert render.fused_plan(_g_query, [net]) == (10, 4, 0)
+    finally:
+        del g["embed_fn"], g["embeddirs_fn"]
+
+
 def _fused_dispatch_detection():
     from swnerf import embedder, model, render, render_dnerf
     e10, c10 = embedder.get_embedder(10, 3, 0)
