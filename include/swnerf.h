@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 100
+#define SWNERF_VERSION 101
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -118,19 +118,23 @@ int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M,
 
 /* ---- training path of the MLP (autograd of model.py:39-62) -----------------
  * forward_train: as swnerf_mlp_forward (SWNERF_NET_CANON) and additionally saves, per row, the
- *   activations the backward needs: act [M, swnerf_act_floats_per_row()] row-major
- *   (h_l post-ReLU at column 256*l, l=0..7; feature_linear output at 2048; views hidden at 2304).
+ *   activations the weight-gradient GEMMs need: act [M, swnerf_act_floats_per_row()] row-major
+ *   (h_l post-ReLU at column 256*l, l=0..7; feature_linear output at 2048; views hidden at 2304), and the
+ *   ReLU bit masks of every 32-row tile: bits [swnerf_mask_floats(M)] (1 KiB per tile and layer; opaque,
+ *   only the backward_dx entry points read it).
  * pack_net_bwd: the transposed weight stream of the dX chain (params as for swnerf_pack_net, first 24).
- * backward_dx: d_out [M,4] = d raw -> grad [M, same layout as act] = d(pre-activation) of every layer.
+ * backward_dx: bits from forward_train, d_out [M,4] = d raw -> grad [M, same layout as act] =
+ *   d(pre-activation) of every layer.
  * gemm_tn: C[No,ldc] += A[M,lda]^T . B[M,ldb] (first No / Ni columns), bias[No] += column sums of A
  *   (bias may be NULL): dW and db of one Linear layer from `grad` and `act`/inputs.  C and bias accumulate:
  *   zero them first.  No <= 256. */
 size_t swnerf_packed_bwd_floats(void);
 size_t swnerf_act_floats_per_row(void);
+size_t swnerf_mask_floats(int64_t M);
 int swnerf_mlp_forward_train(const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
-                             float* out /*[M,4]*/, float* act, void* stream);
+                             float* out /*[M,4]*/, float* act, float* bits, void* stream);
 int swnerf_pack_net_bwd(const float* const* params /*HOST*/, int L_pos, int L_dir, float* packed_bwd, void* stream);
-int swnerf_mlp_backward_dx(const float* packed_bwd, const float* act, const float* d_out /*[M,4]*/, int64_t M,
+int swnerf_mlp_backward_dx(const float* packed_bwd, const float* bits, const float* d_out /*[M,4]*/, int64_t M,
                            float* grad, void* stream);
 int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
                    float* C, int ldc, float* bias, void* stream);
@@ -147,10 +151,11 @@ int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int
  *   SWNERF_BWD_DEFORM           `_time.1..7` trunk columns + `_time_out.weight` (params: the 18 tensors
  *                               _time.0.weight, _time.0.bias, ..., _time_out.weight, _time_out.bias)
  * deform_forward_train: packed = a SWNERF_NET_DNERF blob; x [M,C] as for swnerf_mlp_forward, t_emb [M,1+2*L_time];
- *   writes dx [M,3] and act_d [M, swnerf_act_floats_per_row()] (h_l of `_time` at column 256*l).
+ *   writes dx [M,3], act_d [M, swnerf_act_floats_per_row()] (h_l of `_time` at column 256*l) and
+ *   bits_d [swnerf_mask_floats(M)].
  * backward_dx_pts: as swnerf_mlp_backward_dx with a SWNERF_BWD_CANON_INPUT_GRAD stream; pts [M,3] = the
  *   positions that were embedded (x + dx); also writes d_pts [M,3].
- * deform_backward_dx: d_dx [M,3] -> grad_d [M, same layout as act_d] = d(pre-activation) of `_time.l`. */
+ * deform_backward_dx: bits_d, d_dx [M,3] -> grad_d [M, same layout as act_d] = d(pre-activation) of `_time.l`. */
 #define SWNERF_BWD_CANON 0
 #define SWNERF_BWD_CANON_INPUT_GRAD 1
 #define SWNERF_BWD_DEFORM 2
@@ -158,11 +163,11 @@ size_t swnerf_packed_bwd_floats_kind(int bwd_kind);
 int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
                              float* packed_bwd, void* stream);
 int swnerf_deform_forward_train(const float* packed, const float* x, const float* t_emb, int64_t M,
-                                int L_pos, int L_dir, int L_time, float* dx /*[M,3]*/, float* act_d, void* stream);
-int swnerf_mlp_backward_dx_pts(const float* packed_bwd, const float* act, const float* d_out /*[M,4]*/,
+                                int L_pos, int L_dir, int L_time, float* dx /*[M,3]*/, float* act_d, float* bits_d, void* stream);
+int swnerf_mlp_backward_dx_pts(const float* packed_bwd, const float* bits, const float* d_out /*[M,4]*/,
                                const float* pts /*[M,3]*/, int64_t M, int L_pos,
                                float* grad, float* d_pts /*[M,3]*/, void* stream);
-int swnerf_deform_backward_dx(const float* packed_bwd, const float* act_d, const float* d_dx /*[M,3]*/, int64_t M,
+int swnerf_deform_backward_dx(const float* packed_bwd, const float* bits_d, const float* d_dx /*[M,3]*/, int64_t M,
                               float* grad_d, void* stream);
 
 /* network_query_fn on bare points (nerf/load_model.py:56-74; nerf/extract_mesh.py:27-90, :155-175):

@@ -112,8 +112,21 @@ __device__ __forceinline__ void seg_init_read(f32x16& b, const WStream& ws, int 
     }
 }
 
-template <int S, int NS, int NT, int KT, int INIT>
-__device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, f32x16& binit, float scale) {
+// Side stores (training kernels): while a segment runs, its B operand `kin` - the previous layer's activations, or
+// in the backward chain the gradient just masked - is written to a row-major [M, ld] buffer, ONE 16-byte store
+// every few steps, right behind a step's weight DMA.  Issued as a burst at a layer boundary the same stores
+// stall the wave twice: 32 KB per wave from all 1024 waves at once queue at HBM, and `vmcnt` retires in order, so
+// the next counted wait sits behind every one of them.  Spread out they average ~1 TB/s and hide under the MFMAs.
+// sp: this lane's row base (+ 4h); register r = 4g+e of k-tile n is feature 32n + 8g + 4h + e (16 contiguous bytes).
+// mp/mv: one more 16-byte store at step 1 (the ReLU bit mask of the tile, see relu_bits).
+struct SideStore {
+    float* sp;
+    float* mp; f32x4 mv;
+};
+
+template <int S, int NS, int NT, int KT, int INIT, int SK>
+__device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, f32x16& binit, float scale,
+                                          const SideStore& ss) {
     if constexpr (S < NS) {
         constexpr int n = S / (KT * 4), kt = (S / 4) % KT, q = S % 4;
         constexpr int slot = S % SW_RING, nslot = (S + 1) % SW_RING;
@@ -143,8 +156,21 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
         __builtin_amdgcn_sched_barrier(0);       // ... and the refill BEHIND them (WAR on the slot)
         // refill the slot of step S (read during step S-1) with step S + SW_RING
         ws_dma(ws.base + (S + SW_RING) * 1024, ws.voff, ws.lds_addr + slot * 1024);
+        if constexpr (SK > 0) {
+            constexpr int total = 4 * SK, every = NS / total;
+            static_assert(every >= 1, "segment too short for its side stores");
+            if constexpr (S % every == every - 1 && S / every < total) {
+                constexpr int idx = S / every, n2 = idx / 4, g = idx % 4;
+                const f32x4 v = {kin[n2][4 * g], kin[n2][4 * g + 1], kin[n2][4 * g + 2], kin[n2][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(ss.sp + 32 * n2 + 8 * g) = v;
+            }
+            if constexpr (S == 1) {
+                if (ss.mp) *reinterpret_cast<f32x4*>(ss.mp) = ss.mv;      // wave-uniform condition
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the store stays HERE, not bunched up by the scheduler
+        }
         ws.a_cur = a_next;
-        seg_steps<S + 1, NS, NT, KT, INIT>(out, kin, ws, binit, scale);
+        seg_steps<S + 1, NS, NT, KT, INIT, SK>(out, kin, ws, binit, scale, ss);
     }
 }
 
@@ -152,15 +178,52 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
 // INIT: how the accumulators start -
 //   SEG_ACC (false) keep accumulating | SEG_BIAS (true) the bias tile (so no separate bias pass) |
 //   SEG_ZERO zeros | SEG_BIAS_SCALED the bias tile times a per-lane scalar (backward: w_alpha * d sigma)
-template <int NT, int KT, int INIT>
-__device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, float scale = 1.f) {
+// SK > 0: the first SK k-tiles of `kin` are written out through `ss` while the segment runs (SideStore).
+template <int NT, int KT, int INIT, int SK = 0>
+__device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[KT], WStream& ws, float scale = 1.f,
+                                         const SideStore& ss = SideStore{nullptr, nullptr, {0.f, 0.f, 0.f, 0.f}}) {
     constexpr int NS = NT * KT * 4;
     static_assert(NS % SW_RING == 0, "segment must keep the ring phase");
     f32x16 binit;
     seg_init_read<INIT>(binit, ws, 0);
-    seg_steps<0, NS, NT, KT, INIT>(out, kin, ws, binit, scale);
+    seg_steps<0, NS, NT, KT, INIT, SK>(out, kin, ws, binit, scale, ss);
     if (INIT == SEG_BIAS || INIT == SEG_BIAS_SCALED) ws.bias += NT * SW_BIAS_TILE_FLOATS;
     ws.base += NS * 1024;
+}
+
+// ---- ReLU bit masks (training) -----------------------------------------------------------------------
+// One bit per activation of a 32-row x 256-feature tile: lane (j,h) packs its 8 x 16 values into 4 dwords, bit
+// 16*(n&1) + r of dword n>>1 = (t[n][r] > 0).  64 lanes x 16 B = 1 KiB per (tile, layer): exactly one LDS-DMA
+// step, which is how the backward chain fetches it (compiler-invisible, no exposed load latency) instead of
+// re-reading 32 KiB of activations per layer just for their signs.
+#define SW_MASK_LAYERS 9                          // h_0..h_7, views hidden (the deformation net uses the first 8)
+#define SW_MASK_TILE_FLOATS (SW_MASK_LAYERS * 256)
+template <int NT>
+__device__ __forceinline__ f32x4 relu_bits(const f32x16 (&t)[NT]) {
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // (int)bits clamped to [0,1]: 1 for positive floats, 0 for +0 and for -0 (sign bit = negative int)
+            const int b = min(max(__float_as_int(t[n][r]), 0), 1);
+            m[n >> 1] |= (unsigned)b << (16 * (n & 1) + r);
+        }
+    f32x4 v = {__uint_as_float(m[0]), __uint_as_float(m[1]), __uint_as_float(m[2]), __uint_as_float(m[3])};
+    return v;
+}
+
+// t[n][r] = bit ? t[n][r] : 0
+template <int NT>
+__device__ __forceinline__ void mask_apply(const f32x4& mv, f32x16 (&t)[NT]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = __float_as_int(mv[n >> 1]);
+            const int keep = (m << (31 - (16 * (n & 1) + r))) >> 31;         // 0 or -1
+            t[n][r] = __int_as_float(__float_as_int(t[n][r]) & keep);
+        }
 }
 
 // ReLU as ONE v_max_f32: fmaxf(x, 0.f) costs two (hipcc first canonicalises x with v_max x,x because IEEE
@@ -200,32 +263,17 @@ __device__ __forceinline__ void head_valu(const f32x16 (&x)[NT], WStream& ws, fl
     ws.bias += NOUT * NT * SW_BIAS_TILE_FLOATS;
 }
 
-// ---- activation tiles <-> row-major [M, ld] buffers (training path) ------------------------------
-// register r = 4g+e of lane (j,h) of tile n is feature 32n + 8g + 4h + e of row j: 16 contiguous bytes
+// ---- activation tiles -> a row of a row-major [M, ld] buffer (training path) ---------------------
+// register r = 4g+e of lane (j,h) of tile n is feature 32n + 8g + 4h + e of row j: 16 contiguous bytes.
+// rowp = base + row*ld + 4h.  (Lanes past M use row M-1: they carry copies of that row, the stores are benign.)
 template <int NT>
-__device__ __forceinline__ void tiles_store(float* base, int64_t row, int ld, bool live, int h, const f32x16 (&t)[NT]) {
-    if (!live) return;
-    float* p = base + row * ld + 4 * h;
+__device__ __forceinline__ void tiles_store(float* rowp, const f32x16 (&t)[NT]) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v = {t[n][4 * g], t[n][4 * g + 1], t[n][4 * g + 2], t[n][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(p + 32 * n + 8 * g) = v;
-        }
-}
-
-// t[n][r] = (act[row][32n + feature(r,h)] > 0) ? t[n][r] : 0     (ReLU backward mask from the stored activation)
-template <int NT>
-__device__ __forceinline__ void tiles_mask(const float* base, int64_t row, int ld, int h, f32x16 (&t)[NT]) {
-    const float* p = base + row * ld + 4 * h;
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p + 32 * n + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[n][4 * g + e] = (a[e] > 0.f) ? t[n][4 * g + e] : 0.f;
+            *reinterpret_cast<f32x4*>(rowp + 32 * n + 8 * g) = v;
         }
 }
 
@@ -309,13 +357,18 @@ __device__ __forceinline__ void tile_fetch(const float* lds_tile, int lane, f32x
 // deform_pass: layer 0 also takes the time-embedding k-tile (model.py:129: cat[new_pts, t]).
 // Returns with `in` = relu(layer-7 output) and head[0..2] = the head applied to it on every lane:
 // alpha_linear (head[0] = sigma) for the canonical net, _time_out (dx) for the deformation net.
-// TRAIN: also stores every layer's post-ReLU activation to act[arow][256*l ...] (row-major, ld SW_ACT_LD).
+// TRAIN: every layer's post-ReLU activation h_l goes to act_row[256*l ...] (this lane's row of the row-major
+// [M, SW_ACT_LD] buffer, + 4h) and its ReLU bit mask to mask_tile[256*l] (this lane's 16 bytes of the tile's
+// SW_MASK_TILE_FLOATS), both as side stores of the NEXT segment, whose B operand h_l is.  h_7 has no next
+// segment here: store_last writes it on the spot, otherwise the caller side-stores it (in `in`, mask in *mb).
 template <bool DNERF, bool TRAIN = false>
 __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_emb, float t, bool deform_pass, int h,
                                            f32x16 (&in)[8], f32x16 (&out)[8], float (&head)[3], WStream& ws,
-                                           float* act = nullptr, int64_t arow = 0, bool alive = false) {
+                                           float* act_row = nullptr, float* mask_tile = nullptr, bool store_last = false,
+                                           f32x4* mb = nullptr) {
     const int lane_ = threadIdx.x & 63;
     emb_park(lds_emb, lane_, emb);
+    f32x4 mbits = {0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
@@ -328,7 +381,12 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
                 seg_mfma<8, 2, SEG_BIAS>(out, emb, ws);
             }
         } else {
-            seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
+            if (TRAIN) {
+                const SideStore ss{act_row + 256 * (l - 1), mask_tile + 256 * (l - 1), mbits};
+                seg_mfma<8, 8, SEG_BIAS, TRAIN ? 8 : 0>(out, in, ws, 1.f, ss);
+            } else {
+                seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
+            }
             if (l == 5) {                                        // skip: cat[input_pts, h] (model.py:45-46)
                 f32x16 e2[2];
                 emb_fetch(lds_emb, lane_, e2);
@@ -339,7 +397,15 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
         for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) in[n][r] = relu1(out[n][r]);
-        if (TRAIN) tiles_store<8>(act + 256 * l, arow, SW_ACT_LD, alive, h, in);   // h_l, post-ReLU
+        if (TRAIN) mbits = relu_bits<8>(in);
+    }
+    if (TRAIN) {
+        if (store_last) {
+            tiles_store<8>(act_row + 256 * 7, in);
+            *reinterpret_cast<f32x4*>(mask_tile + 256 * 7) = mbits;
+        } else {
+            *mb = mbits;
+        }
     }
     // head biases: one tile right behind the weight tiles, the same 16 floats in both lane halves:
     // [b_alpha, b_r, b_g, b_b] (canonical) / [b_dx0, b_dx1, b_dx2] (deformation)

@@ -13,7 +13,7 @@ NET_CANON, NET_DNERF = 0, 1
 EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
-           "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
+           "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
            "swnerf_mlp_backward_dx", "swnerf_gemm_tn",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx"]
@@ -75,22 +75,25 @@ def lib():
     L.swnerf_packed_bwd_floats.argtypes = []
     L.swnerf_act_floats_per_row.restype = c_size_t
     L.swnerf_act_floats_per_row.argtypes = []
-    L.swnerf_mlp_forward_train.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_mask_floats.restype = c_size_t
+    L.swnerf_mask_floats.argtypes = [c_int64]
+    L.swnerf_mlp_forward_train.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_pack_net_bwd.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
     L.swnerf_mlp_backward_dx.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     L.swnerf_gemm_tn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]
     L.swnerf_packed_bwd_floats_kind.restype = c_size_t
     L.swnerf_packed_bwd_floats_kind.argtypes = [c_int]
     L.swnerf_pack_net_bwd_kind.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
-    L.swnerf_deform_forward_train.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_deform_forward_train.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_mlp_backward_dx_pts.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
     L.swnerf_deform_backward_dx.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
-                        "swnerf_packed_bwd_floats_kind"):
+                        "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 100:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 100")
+    if L.swnerf_version() != 101:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 101 - rebuild it "
+                           "(python __graft_entry__.py)")
     _lib = L
     return L
 

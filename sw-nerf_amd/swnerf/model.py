@@ -81,24 +81,25 @@ class _MlpTrain(torch.autograd.Function):
         M = x.shape[0]
         out = torch.empty((M, 4), dtype=torch.float32, device=x.device)
         act = torch.empty((M, L.swnerf_act_floats_per_row()), dtype=torch.float32, device=x.device)
+        bits = torch.empty(L.swnerf_mask_floats(M), dtype=torch.float32, device=x.device)
         _lib.check(L.swnerf_mlp_forward_train(_lib.ptr(packed), _lib.ptr(x), M, Lp, Ld, _lib.ptr(out), _lib.ptr(act),
-                                              _lib.stream_of(x)), "mlp_forward_train")
+                                              _lib.ptr(bits), _lib.stream_of(x)), "mlp_forward_train")
         ctx.module, ctx.bands = module, (Lp, Ld)
-        ctx.save_for_backward(x, act, *params)
+        ctx.save_for_backward(x, act, bits, *params)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("swnerf: gradients w.r.t. the embedded inputs are not built (rays are data in train())")
-        x, act, *params = ctx.saved_tensors
+        x, act, bits, *params = ctx.saved_tensors
         module = ctx.module
         L = _lib.lib()
         M = x.shape[0]
         d_out = d_out.contiguous().float()
         grad = torch.empty_like(act)
         st = _lib.stream_of(x)
-        _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(act), _lib.ptr(d_out), M, _lib.ptr(grad), st),
+        _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(bits), _lib.ptr(d_out), M, _lib.ptr(grad), st),
                    "mlp_backward_dx")
         g = [torch.zeros_like(p, dtype=torch.float32) for p in params]      # order: _CANON_ORDER
         _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g)
@@ -122,9 +123,10 @@ class _DnerfTrain(torch.autograd.Function):
         st = _lib.stream_of(x)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         nact = L.swnerf_act_floats_per_row()
-        dx, act_d = new(M, 3), new(M, nact)
+        nbits = L.swnerf_mask_floats(M)
+        dx, act_d, bits_d = new(M, 3), new(M, nact), new(nbits)
         _lib.check(L.swnerf_deform_forward_train(_lib.ptr(packed), _lib.ptr(x), _lib.ptr(t_emb), M, Lp, Ld, Lt,
-                                                 _lib.ptr(dx), _lib.ptr(act_d), st), "deform_forward_train")
+                                                 _lib.ptr(dx), _lib.ptr(act_d), _lib.ptr(bits_d), st), "deform_forward_train")
         Cpos = module.input_ch
         pts2 = x[:, :3] + dx                                                     # model.py:147
         x2 = new(M, x.shape[1])
@@ -132,18 +134,18 @@ class _DnerfTrain(torch.autograd.Function):
         emb = new(M, Cpos)
         _lib.check(L.swnerf_embed(_lib.ptr(pts2), M, 3, Lp, _lib.ptr(emb), st), "embed")   # model.py:148-149
         x2[:, :Cpos] = emb
-        out, act_c = new(M, 4), new(M, nact)
-        _lib.check(L.swnerf_mlp_forward_train(_lib.ptr(occ.packed()[1]), _lib.ptr(x2), M, Lp, Ld, _lib.ptr(out), _lib.ptr(act_c), st),
-                   "mlp_forward_train")
+        out, act_c, bits_c = new(M, 4), new(M, nact), new(nbits)
+        _lib.check(L.swnerf_mlp_forward_train(_lib.ptr(occ.packed()[1]), _lib.ptr(x2), M, Lp, Ld, _lib.ptr(out), _lib.ptr(act_c),
+                                              _lib.ptr(bits_c), st), "mlp_forward_train")
         ctx.module = module
-        ctx.save_for_backward(x, t_emb, x2, pts2, act_d, act_c, *params)
+        ctx.save_for_backward(x, t_emb, x2, pts2, act_d, act_c, bits_d, bits_c, *params)
         return out, dx
 
     @staticmethod
     def backward(ctx, d_out, d_dx):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             raise NotImplementedError("swnerf: gradients w.r.t. the embedded inputs are not built (rays are data in train())")
-        x, t_emb, x2, pts2, act_d, act_c, *params = ctx.saved_tensors
+        x, t_emb, x2, pts2, act_d, act_c, bits_d, bits_c, *params = ctx.saved_tensors
         module = ctx.module
         occ = module._occ
         L = _lib.lib()
@@ -153,13 +155,13 @@ class _DnerfTrain(torch.autograd.Function):
         Cpos, Cdir, Ct = module.input_ch, module.input_ch_views, module.input_ch_time
         d_out = (torch.zeros((M, 4), dtype=torch.float32, device=x.device) if d_out is None else d_out.contiguous().float())
         grad_c, d_pts = torch.empty_like(act_c), torch.empty((M, 3), dtype=torch.float32, device=x.device)
-        _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(act_c), _lib.ptr(d_out),
+        _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(bits_c), _lib.ptr(d_out),
                                                 _lib.ptr(pts2), M, Lp, _lib.ptr(grad_c), _lib.ptr(d_pts), st), "mlp_backward_dx_pts")
         g = [torch.zeros_like(p, dtype=torch.float32) for p in params]
         _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g[:24])
         g_dx = d_pts if d_dx is None else (d_pts + d_dx.float()).contiguous()
         grad_d = torch.empty_like(act_d)
-        _lib.check(L.swnerf_deform_backward_dx(_lib.ptr(module.packed_bwd(_lib.BWD_DEFORM)), _lib.ptr(act_d), _lib.ptr(g_dx), M,
+        _lib.check(L.swnerf_deform_backward_dx(_lib.ptr(module.packed_bwd(_lib.BWD_DEFORM)), _lib.ptr(bits_d), _lib.ptr(g_dx), M,
                                                _lib.ptr(grad_d), st), "deform_backward_dx")
         gd = g[24:]
         mm = lambda A, a_col, No, B, b_col, Ni, wi, c_col, with_bias: _gemm_tn(
