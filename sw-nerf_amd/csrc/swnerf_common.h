@@ -14,7 +14,9 @@
 // One "step" = the A operands of 4 consecutive v_mfma_f32_32x32x2_f32: 64 lanes x float4
 // = 256 floats = 1 KiB, read by ONE global_load_dwordx4 per lane.
 #define SW_STEP_FLOATS 256
+#ifndef SW_RING
 #define SW_RING 8                 // steps kept in flight per wave (prefetch ring)
+#endif
 #define SW_BIAS_TILE_FLOATS 32    // per 32-feature output tile: [h(2)][r(16)]
 
 // steps per segment (NT * KT * 4)
