@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/swnerf.h"
 #include "swnerf_common.h"
+#include "lds_dma.h"
 #include "host_util.h"
 #include <type_traits>
 
@@ -251,6 +252,88 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 256 x 256 case (every trunk layer, feature_linear: 16 of the 28 GEMMs of a training step and ~3/4 of their
+// time): one workgroup of 16 waves owns the WHOLE 256 x 256 block of C for its row slice, so A and B are each read
+// from HBM exactly once, and the 32-row slabs are DOUBLE buffered in 128 KB of LDS, filled by LDS-DMA (no staging
+// registers for hipcc to sink or spill; the next slab is in flight while this one feeds the MFMAs).  One barrier per
+// slab.  Wave w owns the 64 x 64 block o in [64(w&3), +64), i in [64(w>>2), +64) as 2 x 2 accumulator tiles:
+// 4 LDS reads per 4 MFMAs.
+#define GD_SLAB 32
+#define GD_BUF_FLOATS (2 * GD_SLAB * 256)            // A slab then B slab
+__global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
+    extern __shared__ __attribute__((aligned(16))) float gd_lds[];           // [2][GD_BUF_FLOATS]
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int o0 = 64 * (w & 3), i0 = 64 * (w >> 2);
+    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
+    const int nslab = (mlen + GD_SLAB - 1) / GD_SLAB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)gd_lds);
+    const unsigned voff = (unsigned)lane * 16u;
+    // slab s -> buffer s&1: 64 rows of 1 KiB (32 of A, 32 of B), 4 per wave; rows past the slice are clamped to
+    // its last row (never out of bounds) and zeroed on the A side when read
+    auto issue = [&](int sl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = w * 4 + q, row = id & 31;
+            const int64_t r = m0 + min(sl * GD_SLAB + row, mlen - 1);
+            const char* g = reinterpret_cast<const char*>(id < 32 ? P.A + r * P.lda : P.B + r * P.ldb);
+            ws_dma(g, voff, lds0 + (unsigned)((sl & 1) * GD_BUF_FLOATS * 4 + id * 1024));
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    issue(0);
+#pragma nounroll
+    for (int sl = 0; sl < nslab; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+        if (sl + 1 < nslab) issue(sl + 1);
+        const float* As = gd_lds + (sl & 1) * GD_BUF_FLOATS + o0 + i;
+        const float* Bs = gd_lds + (sl & 1) * GD_BUF_FLOATS + GD_SLAB * 256 + i0 + i;
+        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
+        // operands of k-pair s+1 are read while the MFMAs of k-pair s run (pinned: hipcc otherwise reads them right
+        // before use and every group of 4 MFMAs starts with an LDS round trip)
+        float a0 = As[hp * 256], a1 = As[hp * 256 + 32], b0 = Bs[hp * 256], b1 = Bs[hp * 256 + 32];
+#pragma unroll
+        for (int s = 0; s < GD_SLAB / 2; ++s) {
+            const int row = 2 * s + hp;
+            const bool ok = row < valid;                      // one code path: two selects per 4 MFMAs
+            const float c0 = ok ? a0 : 0.f, c1 = ok ? a1 : 0.f, d0 = b0, d1 = b1;
+            if (s + 1 < GD_SLAB / 2) {
+                const int nr = (row + 2) * 256;
+                a0 = As[nr]; a1 = As[nr + 32]; b0 = Bs[nr]; b1 = Bs[nr + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bs0 += c0; bs1 += c1;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d1, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C/D map: register r of lane (j = i, h = hp) of tile (oa, ib) is row o0 + 32 oa + frow(r,h), column i0 + 32 ib + j
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int col = i0 + 32 * (b & 1) + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + 32 * (b >> 1) + sw_frow(r, hp);
+            atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
+        }
+    }
+    if (P.bias && i0 == 0) {
+        bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
+        if (hp == 0) { atomicAdd(P.bias + o0 + i, bs0); atomicAdd(P.bias + o0 + 32 + i, bs1); }
+    }
+}
+
 extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
                               float* C, int ldc, float* bias, void* stream) {
     if (M == 0) return 0;
@@ -258,6 +341,16 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
         return sw_fail(SWNERF_E_ARG, "gemm_tn: bad arguments (M=%lld No=%d Ni=%d lda=%d ldb=%d ldc=%d)", (long long)M, No, Ni, lda, ldb, ldc);
     GemmTN P;
     P.A = A; P.lda = lda; P.No = No; P.B = B; P.ldb = ldb; P.Ni = Ni; P.C = C; P.ldc = ldc; P.bias = bias; P.M = M;
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+    if (aligned && No == 256 && Ni == 256 && M >= 4096) {
+        // one workgroup per CU-sized row slice, whole slabs
+        int64_t nwg = 256;
+        int64_t rows = ((M + nwg - 1) / nwg + GD_SLAB - 1) / GD_SLAB * GD_SLAB;
+        nwg = (M + rows - 1) / rows;
+        P.rows_per_wg = rows;
+        hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)nwg), dim3(1024), 2 * GD_BUF_FLOATS * sizeof(float), (hipStream_t)stream, P);
+        return sw_check(hipGetLastError(), "gemm_tn (dma) launch");
+    }
     // split the rows over ~2 workgroups per CU, at least 256 rows each (whole slabs)
     int64_t nwg = (M + 255) / 256;
     if (nwg > 512) nwg = 512;

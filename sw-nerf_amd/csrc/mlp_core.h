@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "swnerf_common.h"
+#include "lds_dma.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,21 +48,6 @@ struct WStream {
     f32x4 a_cur;             // A operands of the CURRENT step (already read from LDS)
     const float* bias;       // LDS: this lane-half's 16 biases of the CURRENT output tile
 };
-
-// one 1-KiB step: global [gbase + lane*16] -> LDS [lds_addr + lane*16].  M0 carries the LDS
-// base; it is compiler-reserved, so it is saved and restored inside the statement.
-// Write-after-read on the slot: seg_steps issues the DMA (pinned by sched_barrier) AFTER the
-// MFMAs that consumed the slot's previous contents, so that ds_read has returned.
-__device__ __forceinline__ void ws_dma(const char* gbase, unsigned voff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_addr) : "memory");
-}
 
 template <int N>
 __device__ __forceinline__ void ws_wait() {      // all but the N youngest VMEM ops have landed

@@ -255,3 +255,26 @@ def test_dnerf_training_step_with_tv_loss(dev):
     with torch.no_grad():
         after = rd.render_rays(rb(0.5).to(dev), net, q, 64, N_importance=128, white_bkgd=True)["rgb_map"]
     assert float((after - e["rgb_map"].detach()).abs().max()) > 1e-6
+
+
+@pytest.mark.parametrize("M", [4096, 5003, 131072 + 17])
+def test_gemm_tn_256x256_dma_path(dev, M):
+    """The 256x256 weight-gradient GEMM (LDS-DMA double-buffered kernel, taken for M >= 4096) against torch in float64:
+    ragged row counts (last slab partial, last workgroup short), operands that are column windows of wider buffers
+    (lda = ldb = 2432 like `grad` / `act`), accumulation into a non-zero C, and the bias column sums."""
+    from swnerf import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M)
+    A = torch.randn((M, 2432), generator=g).to(dev)
+    B = torch.randn((M, 2432), generator=g).to(dev)
+    C0 = torch.randn((256, 319), generator=g).to(dev)
+    C, bias = C0.clone(), torch.zeros(256, device=dev)
+    st = _lib.stream_of(A)
+    _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * 512, A.stride(0), 256, B.data_ptr() + 4 * 1024, B.stride(0), 256, M,
+                                C.data_ptr() + 4 * 63, C.stride(0), _lib.ptr(bias), st), "gemm_tn")
+    ref = A[:, 512:768].double().T @ B[:, 1024:1280].double()
+    scale = float(ref.abs().max())
+    assert float((C[:, 63:] - C0[:, 63:] - ref.float()).abs().max()) <= 2e-5 * scale
+    assert torch.equal(C[:, :63], C0[:, :63])
+    bref = A[:, 512:768].double().sum(0)
+    assert float((bias - bref.float()).abs().max()) <= 2e-5 * float(bref.abs().max())
