@@ -271,15 +271,30 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
     const int nslab = (mlen + GD_SLAB - 1) / GD_SLAB;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)gd_lds);
     const unsigned voff = (unsigned)lane * 16u;
-    // slab s -> buffer s&1: 64 rows of 1 KiB (32 of A, 32 of B), 4 per wave; rows past the slice are clamped to
-    // its last row (never out of bounds) and zeroed on the A side when read
+    // slab s -> buffer s&1: 64 rows of 1 KiB (32 of A, 32 of B), 4 per wave.  The row pointers advance by one slab
+    // per call (a 64-bit add each; recomputing them costs ~80 dependent scalar instructions per slab, which all
+    // 16 waves execute at the same moment right after the barrier, with the matrix pipe idle).  Rows past the slice
+    // (last slab only) are clamped to its last row - never out of bounds - and zeroed on the A side when read.
+    const char* cur[4];
+    int64_t step[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = w * 4 + q, row = id & 31;
+        cur[q] = reinterpret_cast<const char*>(id < 32 ? P.A + (m0 + row) * P.lda : P.B + (m0 + row) * P.ldb);
+        step[q] = (int64_t)GD_SLAB * 4 * (id < 32 ? P.lda : P.ldb);
+    }
     auto issue = [&](int sl) {
+        const bool full = (sl + 1) * GD_SLAB <= mlen;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int id = w * 4 + q, row = id & 31;
-            const int64_t r = m0 + min(sl * GD_SLAB + row, mlen - 1);
-            const char* g = reinterpret_cast<const char*>(id < 32 ? P.A + r * P.lda : P.B + r * P.ldb);
+            const char* g = cur[q];
+            if (!full) {
+                const int64_t r = m0 + min(sl * GD_SLAB + row, mlen - 1);
+                g = reinterpret_cast<const char*>(id < 32 ? P.A + r * P.lda : P.B + r * P.ldb);
+            }
             ws_dma(g, voff, lds0 + (unsigned)((sl & 1) * GD_BUF_FLOATS * 4 + id * 1024));
+            cur[q] += step[q];
         }
     };
     f32x16 acc[4];
@@ -293,13 +308,14 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
     for (int sl = 0; sl < nslab; ++sl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        if (sl + 1 < nslab) issue(sl + 1);
         const float* As = gd_lds + (sl & 1) * GD_BUF_FLOATS + o0 + i;
         const float* Bs = gd_lds + (sl & 1) * GD_BUF_FLOATS + GD_SLAB * 256 + i0 + i;
         const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
-        // operands of k-pair s+1 are read while the MFMAs of k-pair s run (pinned: hipcc otherwise reads them right
-        // before use and every group of 4 MFMAs starts with an LDS round trip)
+        // operands of k-pair s+1 are read while the MFMAs of k-pair s run; the first reads go out BEFORE the next
+        // slab's DMA is issued, so that its scalar address work hides under their LDS latency
         float a0 = As[hp * 256], a1 = As[hp * 256 + 32], b0 = Bs[hp * 256], b1 = Bs[hp * 256 + 32];
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl + 1 < nslab) issue(sl + 1);
 #pragma unroll
         for (int s = 0; s < GD_SLAB / 2; ++s) {
             const int row = 2 * s + hp;
