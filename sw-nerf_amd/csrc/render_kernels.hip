@@ -27,7 +27,8 @@ struct PassDev {
     int sort_n;             // power of two >= S + n_importance
 };
 #define SW_LDS_BIAS_FLOATS ((SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
-#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS)   // per wave: weight ring + parked embedding
+#define SW_ZSLOT_FLOATS 128          // per wave: two 64-float slots for the next tile's depths (fine pass)
+#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS)   // per wave: weight ring + parked embedding + depths
 #define SW_LDS_FIXED_FLOATS (SW_LDS_BIAS_FLOATS + 4 * SW_LDS_RING_FLOATS)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -95,6 +96,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     WStream ws;
     ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
+    const float* zrow = a.z_vals ? a.z_vals + ray * S : nullptr;
+    const float* zslot = lds_emb + SW_EMB_LDS_FLOATS;
+    const unsigned zslot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)zslot);
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
     double Tc = 1.0;                              // transmittance carried across tiles
     const int ntiles = (S + 31) >> 5;
@@ -103,8 +107,21 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         const int s = tile * 32 + j;
         const bool live = s < S;
         const int sc = live ? s : S - 1;
-        const float z = z_sample(a, ray, near, far, sc);
-        const float zn = (s + 1 < S) ? z_sample(a, ray, near, far, s + 1) : z;
+        float z, zn;
+        if (zrow && tile > 0) {
+            // depths given (fine pass): fetched by LDS-DMA while the previous tile's MLP ran - issued before that
+            // tile's weight stream, so long landed - instead of a global load whose latency every tile would expose
+            const float* zs = zslot + (tile & 1) * 64;
+            z = zs[j];
+            const float z1 = zs[j + 1];
+            zn = (s + 1 < S) ? z1 : z;
+        } else {
+            z = z_sample(a, ray, near, far, sc);
+            zn = (s + 1 < S) ? z_sample(a, ray, near, far, s + 1) : z;
+        }
+        if (zrow && tile + 1 < ntiles)
+            lds_dma_dword(reinterpret_cast<const char*>(zrow), (unsigned)min(32 * (tile + 1) + lane, S - 1) * 4u,
+                          zslot_addr + (unsigned)((tile + 1) & 1) * 256u);
         // pts = rays_o + rays_d * z  (two roundings, nerf/run.py:385)
         float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
 

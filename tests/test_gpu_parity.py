@@ -534,7 +534,10 @@ def test_errors_are_loud(sw, dev, nets):
     rc = _lib.lib().swnerf_render_pass(a, None)
     assert rc == -1 and b"NULL" in _lib.lib().swnerf_last_error()
     with torch.enable_grad():
-        te = torch.zeros((8, 21), device=dev)
-        y, _ = nets["dn"](T(g["x"][:8]).to(dev), [te, te])      # D-NeRF backward is not built yet: loud, not silent
-        with pytest.raises(NotImplementedError, match="backward"):
+        # gradients w.r.t. the embedded inputs are not built (rays are data in train()): loud, not silently zero
+        x = T(g["x"][:8]).to(dev).requires_grad_(True)
+        y = nets["fine"](x)
+        with pytest.raises(NotImplementedError, match="embedded inputs"):
             y.sum().backward()
+        for p_ in nets["fine"].parameters():
+            p_.grad = None
