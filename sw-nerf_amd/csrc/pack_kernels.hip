@@ -173,7 +173,7 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
         pk.vecs(params[22], 3, 128);                                               // rgb_linear.weight
     };
     auto tail = [&](float* wbase, const float* head) {
-        return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
+        return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
     };
 
     int rc = 0;
@@ -222,7 +222,7 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
     auto tail = [&](Packer& pk, size_t steps) {
         if (pk.rc) return pk.rc;
         if (pk.w != packed_bwd + steps * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: internal layout mismatch");
-        return sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_RING * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
+        return sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
     };
     if (bwd_kind == SWNERF_BWD_DEFORM) {
         Packer pk{st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, L_dir, 0, 0};

@@ -13,6 +13,7 @@
 #include "swnerf_common.h"
 #include "mlp_core.h"
 #include "host_util.h"
+#include "mlp_kernels.h"
 
 #define SW_LDS_SC 256                    // max coarse samples when resampling
 #define SW_LDS_SORT 1024                 // max S + n_importance (padded to a power of two)
@@ -26,10 +27,6 @@ struct PassDev {
     int two_pass;           // 1: deformation net then canonical net
     int sort_n;             // power of two >= S + n_importance
 };
-#define SW_LDS_BIAS_FLOATS ((SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
-#define SW_ZSLOT_FLOATS 128          // per wave: two 64-float slots for the next tile's depths (fine pass)
-#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS)   // per wave: weight ring + parked embedding + depths
-#define SW_LDS_FIXED_FLOATS (SW_LDS_BIAS_FLOATS + 4 * SW_LDS_RING_FLOATS)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -278,91 +275,6 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
 }
 
 // ------------------------------------------------------------------------------------------
-// model.forward(x) on already-embedded rows (API parity with run_network / extract_mesh):
-// one wave per 32 rows; the embedded features are gathered from x into the B-operand slots.
-struct MlpDev {
-    const float* x; int64_t M; int C;   // C = C_pos + C_dir
-    int Lp, Ld, Lt, Cpos;
-    const float* t_emb; int Ct;
-    const float* w0; const float* b0; int nbias; int two_pass;
-    float* out; float* dx;
-    float* act;             // TRAIN: [M, SW_ACT_LD] activations saved for the backward pass
-    float* bits;            // TRAIN: [ceil(M/32), SW_MASK_TILE_FLOATS] ReLU bit masks (mlp_core.h relu_bits)
-};
-
-template <bool DNERF, bool TRAIN = false>
-__global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
-    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
-    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_bias, P.b0, P.nbias);
-    if (tile * 32 >= P.M) return;
-    const int64_t row = tile * 32 + j;
-    const bool live = row < P.M;
-    const float* xr = P.x + (live ? row : P.M - 1) * P.C;
-
-    f32x16 emb[2], in[8], out[8];
-    float head[3], rgb[3];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {
-        const int col = sw_pos_col(a, h, P.Lp);
-        emb[a >> 4][a & 15] = (col >= 0) ? xr[col] : 0.f;
-    }
-    float* act_row = TRAIN ? P.act + (live ? row : P.M - 1) * SW_ACT_LD + 4 * h : nullptr;
-    float* mask_tile = TRAIN ? P.bits + tile * SW_MASK_TILE_FLOATS + lane * 4 : nullptr;
-    f32x4 mb = {0.f, 0.f, 0.f, 0.f};
-    WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-    float ex = 0.f, ey = 0.f, ez = 0.f;
-    if (DNERF) {
-        const float ft = P.t_emb ? P.t_emb[(live ? row : P.M - 1) * P.Ct] : 0.f;   // column 0 of gamma(t) is t
-#pragma nounroll
-        for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
-            trunk_pass<true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws);
-            if (pass == 0) {
-                ex = head[0]; ey = head[1]; ez = head[2];
-                pe_pos(xr[0] + ex, xr[1] + ey, xr[2] + ez, h, emb);      // embed_fn(input_pts_orig + dx)
-            }
-        }
-    } else {
-        trunk_pass<false, TRAIN>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb);
-    }
-    // view-direction features: gathered like the position ones
-    const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
-    f32x16 k9[9];
-    if (TRAIN) seg_mfma<8, 8, SEG_BIAS, TRAIN ? 8 : 0>(out, in, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
-    else seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
-#pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = out[n];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        const int col = sw_dir_col(a, h, P.Ld);
-        k9[8][a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
-    }
-    f32x16 hv[4];
-    if (TRAIN) seg_mfma<4, 9, SEG_BIAS, TRAIN ? 8 : 0>(hv, k9, ws, 1.f, SideStore{act_row + SW_ACT_FEAT, nullptr, mb});
-    else seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
-    if (TRAIN) {
-        tiles_store<4>(act_row + SW_ACT_HV, hv);
-        *reinterpret_cast<f32x4*>(mask_tile + 256 * 8) = relu_bits<4>(hv);
-    }
-    head_valu<3, 4>(hv, ws, rgb);
-    rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
-    if (live && h == 0) {
-        f32x4 r4 = {rgb[0], rgb[1], rgb[2], head[0]};
-        *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
-        if (P.dx) { P.dx[row * 3 + 0] = ex; P.dx[row * 3 + 1] = ey; P.dx[row * 3 + 2] = ez; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // network_query_fn on bare points (nerf/load_model.py:56-74) with V view directions per point
 // (nerf/extract_mesh.py:27-90): trunk + density once, view branch V times.
 struct QueryDev {
@@ -418,262 +330,6 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
         f32x4 r4 = {sr * inv, sg * inv, sb * inv, head[0]};
         *reinterpret_cast<f32x4*>(P.out + row * 4) = r4;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward of the MLP w.r.t. its activations (the "dX chain"), one wave per 32 rows, mirroring the
-// forward: transposed weight streams, the same register-resident accumulator->operand hand-over.  The ReLU
-// derivative comes from the forward's bit masks, fetched one layer ahead by LDS-DMA into a 1-KiB slot of the
-// wave (nothing the compiler sees is ever pending, like the weight ring); d(pre-activation) of every layer goes
-// to grad[M, SW_ACT_LD] (same column map as act) for the weight-gradient GEMMs as side stores of the segment
-// that consumes it (mlp_core.h SideStore).   model.py:39-62 reversed.
-struct MaskRing {
-    const char* base;        // wave-uniform: this tile's SW_MASK_TILE_FLOATS of bit masks
-    unsigned voff, lds_addr; // lane * 16; LDS byte address of the slot
-    const float* slot;       // the slot + lane * 4 floats
-};
-__device__ __forceinline__ void mask_start(MaskRing& mr, const float* bits, int64_t tile, float* lds_slot, int lane) {
-    mr.base = reinterpret_cast<const char*>(bits + tile * SW_MASK_TILE_FLOATS);
-    mr.voff = (unsigned)lane * 16u;
-    mr.lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_slot);
-    mr.slot = lds_slot + lane * 4;
-}
-// fetch layer l's mask; the previous contents must have been read (mask_take ends with lgkmcnt(0))
-__device__ __forceinline__ void mask_fetch(const MaskRing& mr, int l) { ws_dma(mr.base + l * 1024, mr.voff, mr.lds_addr); }
-// the mask fetched last; legal once a counted wait behind >= SW_RING later DMAs has passed (any full segment)
-__device__ __forceinline__ f32x4 mask_take(const MaskRing& mr) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(mr.slot);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return v;
-}
-
-struct DxDev {
-    const float* w0; const float* b0;      // backward stream; its 8 "bias" tiles = alpha_linear.weight
-    const float* bits; const float* d_out; // [ceil(M/32), SW_MASK_TILE_FLOATS], [M,4]
-    int64_t M; float* grad;
-    const float* pts; float* d_pts; int Lp; // INGRAD: the embedded positions [M,3], their gradient [M,3]
-};
-
-// INGRAD: also d gamma(x) = pts_linears.5.weight[:, :Cpos]^T . d pre_5 + pts_linears.0.weight^T . d pre_0 in the
-// slots pe_pos() fills (pack_kernels.hip rowmap), then d x = J_gamma(x)^T . d gamma(x) on the VALU (embedder.py:33-42).
-template <bool INGRAD>
-__global__ void __launch_bounds__(256, 1) mlp_backward_dx_kernel(DxDev P) {
-    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
-    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_bias, P.b0, SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS);
-    if (tile * 32 >= P.M) return;
-    const int64_t row = tile * 32 + j;
-    const bool live = row < P.M;
-    const int64_t rr = live ? row : P.M - 1;
-    const f32x4 dr = *reinterpret_cast<const f32x4*>(P.d_out + rr * 4);     // d rgb(3), d sigma
-    float* grad_row = P.grad + rr * SW_ACT_LD + 4 * h;
-    const f32x4 nomask = {0.f, 0.f, 0.f, 0.f};
-    MaskRing mr;
-    mask_start(mr, P.bits, tile, lds_emb + 2 * 16 * 64, lane);
-    mask_fetch(mr, 8);                                                   // views hidden; older than every weight step
-    WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-    // d hv = rgb_linear.weight^T . d rgb, masked by hv > 0           (4 tiles <- 1 k-tile holding 3 channels)
-    f32x16 k1[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) k1[0][r] = 0.f;
-    k1[0][0] = h ? 0.f : dr[0]; k1[0][1] = h ? 0.f : dr[1]; k1[0][2] = h ? 0.f : dr[2];
-    f32x16 dhv[4];
-    seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
-    mask_apply<4>(mask_take(mr), dhv);
-    mask_fetch(mr, 7);
-    // d feature = views_linears.0.weight[:, :256]^T . d hv            (no activation on feature_linear)
-    f32x16 in[8], out[8];
-    seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
-    // d h7 = feature_linear.weight^T . d feature + alpha_linear.weight * d sigma, masked by h7 > 0
-    seg_mfma<8, 8, SEG_BIAS_SCALED, 8>(out, in, ws, dr[3], SideStore{grad_row + SW_ACT_FEAT, nullptr, nomask});
-#pragma nounroll
-    for (int l = 7; l >= 1; --l) {
-        // out = d h_l;  d pre_l = out . [h_l > 0];  d h_{l-1} = W_l[:, -256:]^T . d pre_l
-#pragma unroll
-        for (int n = 0; n < 8; ++n) in[n] = out[n];
-        mask_apply<8>(mask_take(mr), in);
-        mask_fetch(mr, l - 1);
-        if (INGRAD && l == 5) {                                          // the skip input cat[gamma(x), h4]: its gamma(x) part
-            f32x16 ge[2];
-            seg_mfma<2, 8, SEG_ZERO>(ge, in, ws);
-            emb_park(lds_emb, lane, ge);
-        }
-        seg_mfma<8, 8, SEG_ZERO, 8>(out, in, ws, 1.f, SideStore{grad_row + 256 * l, nullptr, nomask});
-    }
-#pragma unroll
-    for (int n = 0; n < 8; ++n) in[n] = out[n];
-    mask_apply<8>(mask_take(mr), in);                                    // d pre_0
-    if (!INGRAD) {
-        tiles_store<8>(grad_row, in);
-    } else {
-        f32x16 ge[2];
-        emb_fetch(lds_emb, lane, ge);
-        seg_mfma<2, 8, SEG_ACC, 8>(ge, in, ws, 1.f, SideStore{grad_row, nullptr, nomask});
-        // slot a of lane half h holds sin (h=0) / cos (h=1) of 2^k x_c, a = 3k + c < 30; slots 30, 31 hold x itself
-        const float x0 = P.pts[rr * 3], x1 = P.pts[rr * 3 + 1], x2 = P.pts[rr * 3 + 2];
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 30; ++a) {
-            const int k = a / 3, c = a % 3;
-            const float f = (float)(1 << k);
-            const float xc = (c == 0) ? x0 : ((c == 1) ? x1 : x2);
-            float d = sw_sin_or_cos(xc * f, 1 - h) * f;                  // d sin = cos, d cos = -sin
-            d = h ? -d : d;
-            const float t = (k < P.Lp) ? ge[a >> 4][a & 15] * d : 0.f;
-            if (c == 0) g0 += t; else if (c == 1) g1 += t; else g2 += t;
-        }
-        if (h == 0) { g0 += ge[1][14]; g1 += ge[1][15]; } else { g2 += ge[1][14]; }
-        g0 += __shfl_xor(g0, 32, 64); g1 += __shfl_xor(g1, 32, 64); g2 += __shfl_xor(g2, 32, 64);
-        if (live && h == 0) { P.d_pts[row * 3] = g0; P.d_pts[row * 3 + 1] = g1; P.d_pts[row * 3 + 2] = g2; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// DirectTemporalNeRF training: the deformation net alone, saving its activations (model.py:128-136).
-struct DeformDev {
-    const float* x; const float* t_emb; int64_t M; int C, Lp, Ct;
-    const float* w0; const float* b0; int nbias;
-    float* dx; float* act; float* bits;
-};
-
-__global__ void __launch_bounds__(256, 1) deform_forward_train_kernel(DeformDev P) {
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
-    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
-    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_bias, P.b0, P.nbias);
-    if (tile * 32 >= P.M) return;
-    const int64_t row = tile * 32 + j;
-    const bool live = row < P.M;
-    const int64_t rr = live ? row : P.M - 1;
-    const float* xr = P.x + rr * P.C;
-    f32x16 emb[2], in[8], out[8];
-    float head[3];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {
-        const int col = sw_pos_col(a, h, P.Lp);
-        emb[a >> 4][a & 15] = (col >= 0) ? xr[col] : 0.f;
-    }
-    const float ft = P.t_emb[rr * P.Ct];                                  // column 0 of gamma(t) is t
-    WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-    trunk_pass<true, true>(emb, lds_emb, ft, true, h, in, out, head, ws, P.act + rr * SW_ACT_LD + 4 * h,
-                           P.bits + tile * SW_MASK_TILE_FLOATS + lane * 4, true, nullptr);
-    if (live && h == 0) { P.dx[row * 3] = head[0]; P.dx[row * 3 + 1] = head[1]; P.dx[row * 3 + 2] = head[2]; }
-}
-
-// dX chain of the deformation net: d h7 = _time_out.weight^T . d dx, then _time.7 .. _time.1 (model.py:128-136 reversed)
-struct DeformBwdDev {
-    const float* w0; const float* b0;      // SWNERF_BWD_DEFORM stream; its 24 "bias" tiles = _time_out.weight rows
-    const float* bits; const float* d_dx;  // [ceil(M/32), SW_MASK_TILE_FLOATS], [M,3]
-    int64_t M; float* grad;
-};
-
-__global__ void __launch_bounds__(256, 1) deform_backward_dx_kernel(DeformBwdDev P) {
-    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
-    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_bias, P.b0, SW_DBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS);
-    if (tile * 32 >= P.M) return;
-    const int64_t row = tile * 32 + j;
-    const bool live = row < P.M;
-    const int64_t rr = live ? row : P.M - 1;
-    const float d0 = P.d_dx[rr * 3], d1 = P.d_dx[rr * 3 + 1], d2 = P.d_dx[rr * 3 + 2];
-    float* grad_row = P.grad + rr * SW_ACT_LD + 4 * h;
-    const f32x4 nomask = {0.f, 0.f, 0.f, 0.f};
-    MaskRing mr;
-    mask_start(mr, P.bits, tile, lds_emb + 2 * 16 * 64, lane);
-    mask_fetch(mr, 7);
-    WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-    f32x16 in[8], out[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws.bias + (0 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(ws.bias + (1 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(ws.bias + (2 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[n][4 * g + e] = w0[e] * d0 + w1[e] * d1 + w2[e] * d2;
-        }
-#pragma nounroll
-    for (int l = 7; l >= 1; --l) {
-#pragma unroll
-        for (int n = 0; n < 8; ++n) in[n] = out[n];
-        mask_apply<8>(mask_take(mr), in);
-        mask_fetch(mr, l - 1);
-        seg_mfma<8, 8, SEG_ZERO, 8>(out, in, ws, 1.f, SideStore{grad_row + 256 * l, nullptr, nomask});
-    }
-#pragma unroll
-    for (int n = 0; n < 8; ++n) in[n] = out[n];
-    mask_apply<8>(mask_take(mr), in);                                    // d pre_0 (x and t are data: no further gradient)
-    tiles_store<8>(grad_row, in);
-}
-
-extern "C" size_t swnerf_packed_bwd_floats(void) { return (size_t)SW_BWD_FLOATS; }
-extern "C" size_t swnerf_act_floats_per_row(void) { return (size_t)SW_ACT_LD; }
-extern "C" size_t swnerf_mask_floats(int64_t M) { return M <= 0 ? 0 : (size_t)((M + 31) / 32) * SW_MASK_TILE_FLOATS; }
-
-extern "C" int swnerf_mlp_backward_dx(const float* packed_bwd, const float* bits, const float* d_out, int64_t M,
-                                      float* grad, void* stream) {
-    if (M == 0 && packed_bwd) return 0;
-    if (!packed_bwd || !bits || !d_out || !grad || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_backward_dx: NULL pointer or negative M");
-    DxDev P;
-    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_BWD_W_FLOATS; P.bits = bits; P.d_out = d_out; P.M = M; P.grad = grad;
-    P.pts = nullptr; P.d_pts = nullptr; P.Lp = 0;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    hipLaunchKernelGGL(mlp_backward_dx_kernel<false>, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
-    return sw_check(hipGetLastError(), "mlp_backward_dx launch");
-}
-
-extern "C" int swnerf_mlp_backward_dx_pts(const float* packed_bwd, const float* bits, const float* d_out, const float* pts,
-                                          int64_t M, int L_pos, float* grad, float* d_pts, void* stream) {
-    if (M == 0 && packed_bwd) return 0;
-    if (!packed_bwd || !bits || !d_out || !pts || !grad || !d_pts || M < 0)
-        return sw_fail(SWNERF_E_ARG, "mlp_backward_dx_pts: NULL pointer or negative M");
-    if (L_pos < 0 || L_pos > 10) return sw_fail(SWNERF_E_UNSUPP, "mlp_backward_dx_pts: %d position bands exceed 10", L_pos);
-    DxDev P;
-    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_BWD_IG_W_FLOATS; P.bits = bits; P.d_out = d_out; P.M = M; P.grad = grad;
-    P.pts = pts; P.d_pts = d_pts; P.Lp = L_pos;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    hipLaunchKernelGGL(mlp_backward_dx_kernel<true>, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
-    return sw_check(hipGetLastError(), "mlp_backward_dx_pts launch");
-}
-
-extern "C" int swnerf_deform_backward_dx(const float* packed_bwd, const float* bits_d, const float* d_dx, int64_t M,
-                                         float* grad_d, void* stream) {
-    if (M == 0 && packed_bwd) return 0;
-    if (!packed_bwd || !bits_d || !d_dx || !grad_d || M < 0) return sw_fail(SWNERF_E_ARG, "deform_backward_dx: NULL pointer or negative M");
-    DeformBwdDev P;
-    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_DBWD_W_FLOATS; P.bits = bits_d; P.d_dx = d_dx; P.M = M; P.grad = grad_d;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    hipLaunchKernelGGL(deform_backward_dx_kernel, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
-    return sw_check(hipGetLastError(), "deform_backward_dx launch");
-}
-
-// ------------------------------------------------------------------------------------------
-static int stream_ptrs(int kind, const float* packed, int run_deform, const float** w0, const float** b0, int* nbias, int* two) {
-    *nbias = SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
-    if (kind == SWNERF_NET_CANON) {
-        *w0 = packed; *b0 = packed + SW_CANON_W_FLOATS; *two = 0;
-    } else if (kind == SWNERF_NET_DNERF) {
-        if (run_deform) { *w0 = packed; *b0 = packed + SW_DNERF_W_FLOATS; *two = 1; *nbias = SW_LDS_BIAS_FLOATS; }
-        else { const float* c = packed + SW_DNERF_A_FLOATS; *w0 = c; *b0 = c + SW_CANON_W_FLOATS; *two = 0; }
-    } else {
-        return sw_fail(SWNERF_E_ARG, "unknown net kind %d", kind);
-    }
-    return 0;
 }
 
 extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
@@ -745,37 +401,4 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     if (kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(mlp_forward_kernel<true>, grid, block, lds, st, P);
     else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, lds, st, P);
     return sw_check(hipGetLastError(), "mlp_forward launch");
-}
-
-extern "C" int swnerf_mlp_forward_train(const float* packed, const float* x, int64_t M, int L_pos, int L_dir,
-                                        float* out, float* act, float* bits, void* stream) {
-    if (M == 0 && packed) return 0;
-    if (!packed || !x || !out || !act || !bits || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_forward_train: NULL pointer or negative M");
-    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "mlp_forward_train: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
-    MlpDev P;
-    P.x = x; P.M = M; P.Lp = L_pos; P.Ld = L_dir; P.Lt = 0;
-    P.Cpos = 3 * (1 + 2 * L_pos); P.C = P.Cpos + 3 * (1 + 2 * L_dir);
-    P.t_emb = nullptr; P.Ct = 1; P.out = out; P.dx = nullptr; P.act = act; P.bits = bits;
-    int rc = stream_ptrs(SWNERF_NET_CANON, packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
-    if (rc) return rc;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
-    return sw_check(hipGetLastError(), "mlp_forward_train launch");
-}
-
-extern "C" int swnerf_deform_forward_train(const float* packed, const float* x, const float* t_emb, int64_t M,
-                                           int L_pos, int L_dir, int L_time, float* dx, float* act_d, float* bits_d, void* stream) {
-    if (M == 0 && packed) return 0;
-    if (!packed || !x || !t_emb || !dx || !act_d || !bits_d || M < 0) return sw_fail(SWNERF_E_ARG, "deform_forward_train: NULL pointer or negative M");
-    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4 || L_time < 0 || L_time > 10)
-        return sw_fail(SWNERF_E_UNSUPP, "deform_forward_train: embedder bands (%d,%d,%d) exceed (10,4,10)", L_pos, L_dir, L_time);
-    DeformDev P;
-    P.x = x; P.t_emb = t_emb; P.M = M; P.Lp = L_pos; P.C = 3 * (1 + 2 * L_pos) + 3 * (1 + 2 * L_dir); P.Ct = 1 + 2 * L_time;
-    P.dx = dx; P.act = act_d; P.bits = bits_d;
-    int two = 0;
-    int rc = stream_ptrs(SWNERF_NET_DNERF, packed, 1, &P.w0, &P.b0, &P.nbias, &two);
-    if (rc) return rc;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
-    hipLaunchKernelGGL(deform_forward_train_kernel, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
-    return sw_check(hipGetLastError(), "deform_forward_train launch");
 }

@@ -15,8 +15,9 @@
 // = 256 floats = 1 KiB, read by ONE global_load_dwordx4 per lane.
 #define SW_STEP_FLOATS 256
 #ifndef SW_RING
-#define SW_RING 8                 // steps kept in flight per wave (prefetch ring)
+#define SW_RING 8                 // steps kept in flight per wave (prefetch ring); a translation unit may choose 16
 #endif
+#define SW_TAIL 16                // every stream ends with a copy of its first SW_TAIL steps (>= any ring depth)
 #define SW_BIAS_TILE_FLOATS 32    // per 32-feature output tile: [h(2)][r(16)]
 
 // steps per segment (NT * KT * 4)
@@ -39,17 +40,17 @@
 #define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
 #define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 24 + 1)
 
-// blob CANON : [canon steps][ring tail = copy of first SW_RING steps][canon bias][views loop]
-// views loop  : [VIEWS steps][tail = copy of the first SW_RING VIEWS steps] - the view
+// blob CANON : [canon steps][ring tail = copy of first SW_TAIL steps][canon bias][views loop]
+// views loop  : [VIEWS steps][tail = copy of the first SW_TAIL VIEWS steps] - the view
 //               branch as a stream that wraps onto itself, for queries of many view directions per
 //               point (swnerf_query_points: trunk and density once, view branch V times)
-#define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_CANON_VL_OFFSET  (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
-#define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_RING) * SW_STEP_FLOATS)
+#define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_CANON_FLOATS     (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
 // blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
 // (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
-#define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_DNERF_A_FLOATS   (SW_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
 #define SW_DNERF_FLOATS     (SW_DNERF_A_FLOATS + SW_CANON_FLOATS)
 
@@ -61,17 +62,17 @@
 // backward weight stream (transposed weights, execution order of the dX chain):
 // RGB^T (4x1) | VIEWS^T (8x4) | FEAT^T (8x8) | L7^T .. L1^T (8x8 each); then the alpha_linear weight as 8 bias tiles
 #define SW_BWD_STEPS (16 + 128 + 256 + 7 * 256)
-#define SW_BWD_W_FLOATS ((SW_BWD_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_BWD_W_FLOATS ((SW_BWD_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_BWD_BIAS_TILES 8
 #define SW_BWD_FLOATS (SW_BWD_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 // ... with the gradient w.r.t. the embedded positions (D-NeRF training: it flows on into the deformation net):
 // RGB^T | VIEWS^T | FEAT^T | L7^T L6^T | L5[:, :Cpos]^T (2x8) | L5[:, Cpos:]^T | L4^T .. L1^T | L0^T (2x8)
 #define SW_BWD_IG_STEPS (SW_BWD_STEPS + 2 * 64)
-#define SW_BWD_IG_W_FLOATS ((SW_BWD_IG_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_BWD_IG_W_FLOATS ((SW_BWD_IG_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_BWD_IG_FLOATS (SW_BWD_IG_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 // deformation net (`_time`): L7^T .. L1^T (trunk columns); then _time_out.weight [3,256] as 3 x 8 bias tiles
 #define SW_DBWD_STEPS (7 * 256)
-#define SW_DBWD_W_FLOATS ((SW_DBWD_STEPS + SW_RING) * SW_STEP_FLOATS)
+#define SW_DBWD_W_FLOATS ((SW_DBWD_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_DBWD_BIAS_TILES 24
 #define SW_DBWD_FLOATS (SW_DBWD_W_FLOATS + SW_DBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 

@@ -51,8 +51,8 @@ def test_pass_args_layout_matches_c(built, tmp_path):
 
 def test_packed_sizes_and_argument_errors_without_gpu(built):
     L = built.lib()
-    canon = (2320 + 8) * 256 + 97 * 32 + (144 + 8) * 256               # stream + tail, bias/head tiles, views loop
-    dnerf = (1952 + 2320 + 8) * 256 + (89 + 97) * 32 + canon
+    canon = (2320 + 16) * 256 + 97 * 32 + (144 + 16) * 256             # stream + tail, bias/head tiles, views loop
+    dnerf = (1952 + 2320 + 16) * 256 + (89 + 97) * 32 + canon
     assert L.swnerf_packed_floats(0) == canon and L.swnerf_packed_floats(1) == dnerf and L.swnerf_packed_floats(7) == 0
     # pure argument validation happens before any device call
     assert L.swnerf_render_pass(None, None) == -1 and b"NULL" in L.swnerf_last_error()
