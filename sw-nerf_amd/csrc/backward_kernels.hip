@@ -134,9 +134,9 @@ struct GemmTN { const float* A; int lda; int No; const float* B; int ldb; int Ni
 // matrix work comes from 2-3 co-resident workgroups per CU (one loads while another computes), not from a
 // register prefetch: hipcc spills a prefetched slab to scratch at this register budget (load -> vmcnt(0) ->
 // scratch_store), and scratch traffic shares vmcnt with everything else.
-// VEC4: both operands 16-byte aligned with column counts multiples of 4 (every 256/128-wide GEMM) -> float4
-// loads; otherwise 4-byte loads with column masks (x[:, :63] with ld 90, d_out[:, 3] with ld 4).
-template <bool VEC4>
+// VA / VB: that operand is 16-byte aligned with a column count that is a multiple of 4 -> float4 loads; otherwise
+// 4-byte loads with column masks.
+template <bool VA, bool VB>
 __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
     __shared__ __attribute__((aligned(16))) float As[GT_SLAB][128];
     __shared__ __attribute__((aligned(16))) float Bs[GT_SLAB][256];
@@ -162,50 +162,62 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
         // columns outside the problem are zeroed at the LDS write.  (A load under `if` becomes a branch with its
         // LDS write right behind it: one serialised memory round trip per load - measured 6 us per slab.)
         const unsigned rlast = (unsigned)(mlen - 1 - mrel);
-        if (VEC4) {
-            f32x4 va[2], vb[4];
+        // per operand: 16-byte loads when its base, leading dimension and column count allow (VA / VB), else 4-byte
+        // loads with column masks (x[:, :63] with ld 90, d_out[:, 3] with ld 4).  Mixed cases matter: the narrow GEMMs
+        // pair one such operand with a 256-wide window of grad/act, which is most of their traffic.
+        f32x4 va4[VA ? 2 : 1], vb4[VB ? 4 : 1];
+        float va1[VA ? 1 : 8], vb1[VB ? 1 : 16];
+        if (VA) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {            // A: 32 x 128 floats = 1024 float4
                 const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
-                va[k] = *reinterpret_cast<const f32x4*>(Ab + (mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c4 < P.No) ? c4 : 0));
+                va4[k] = *reinterpret_cast<const f32x4*>(Ab + (mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c4 < P.No) ? c4 : 0));
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = t + 512 * k, row = f >> 7, c = f & 127;
+                va1[k] = Ab[(mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c < P.No) ? c : 0)];
+            }
+        }
+        if (VB) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {            // B: 32 x 256 floats = 2048 float4
                 const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
-                vb[k] = *reinterpret_cast<const f32x4*>(Bb + (mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c4 < P.Ni) ? c4 : 0));
+                vb4[k] = *reinterpret_cast<const f32x4*>(Bb + (mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c4 < P.Ni) ? c4 : 0));
             }
-            const f32x4 z = {};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int f = t + 512 * k, row = f >> 8, c = f & 255;
+                vb1[k] = Bb[(mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c < P.Ni) ? c : 0)];
+            }
+        }
+        const f32x4 z = {};
+        if (VA) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
-                *reinterpret_cast<f32x4*>(&As[row][c4]) = ((unsigned)row <= rlast && obase + c4 < P.No) ? va[k] : z;
+                *reinterpret_cast<f32x4*>(&As[row][c4]) = ((unsigned)row <= rlast && obase + c4 < P.No) ? va4[k] : z;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int f = t + 512 * k, row = f >> 7, c = f & 127;
+                As[row][c] = ((unsigned)row <= rlast && obase + c < P.No) ? va1[k] : 0.f;
+            }
+        }
+        if (VB) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
-                *reinterpret_cast<f32x4*>(&Bs[row][c4]) = ((unsigned)row <= rlast && i0 + c4 < P.Ni) ? vb[k] : z;
+                *reinterpret_cast<f32x4*>(&Bs[row][c4]) = ((unsigned)row <= rlast && i0 + c4 < P.Ni) ? vb4[k] : z;
             }
         } else {
-            float va[8], vb[16];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int f = t + 512 * k, row = f >> 7, c = f & 127;
-                va[k] = Ab[(mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c < P.No) ? c : 0)];
-            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int f = t + 512 * k, row = f >> 8, c = f & 255;
-                vb[k] = Bb[(mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c < P.Ni) ? c : 0)];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int f = t + 512 * k, row = f >> 7, c = f & 127;
-                As[row][c] = ((unsigned)row <= rlast && obase + c < P.No) ? va[k] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int f = t + 512 * k, row = f >> 8, c = f & 255;
-                Bs[row][c] = ((unsigned)row <= rlast && i0 + c < P.Ni) ? vb[k] : 0.f;
+                Bs[row][c] = ((unsigned)row <= rlast && i0 + c < P.Ni) ? vb1[k] : 0.f;
             }
         }
         __syncthreads();
@@ -376,9 +388,12 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
     nwg = (M + rows - 1) / rows;
     if (rows * (int64_t)(lda > ldb ? lda : ldb) >= (1LL << 31)) return sw_fail(SWNERF_E_UNSUPP, "gemm_tn: row slice too large for 32-bit offsets");
     const dim3 grid((unsigned)nwg, (unsigned)(((Ni + 255) / 256) * (No > 128 ? 2 : 1))), block(512);
-    const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && (No % 4 == 0) && (Ni % 4 == 0) &&
-                      (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
-    if (vec4) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
+    const bool va = (lda % 4 == 0) && (No % 4 == 0) && ((uintptr_t)A % 16 == 0);
+    const bool vb = (ldb % 4 == 0) && (Ni % 4 == 0) && ((uintptr_t)B % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (va && vb) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, block, 0, st, P);
+    else if (va) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, block, 0, st, P);
+    else if (vb) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, 0, st, P);
     return sw_check(hipGetLastError(), "gemm_tn launch");
 }
