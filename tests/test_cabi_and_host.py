@@ -61,6 +61,18 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     assert b"degenerate" in L.swnerf_last_error()
     assert L.swnerf_sample_pdf(None, None, 4, 5000, 8, None, None, None, 0, None, None, None) != 0
     assert L.swnerf_pack_net(0, None, 10, 4, 0, None, None) == -1
+    # training entry points: stream sizes per kind, bit-mask buffer size, NULL / bad-kind rejection
+    bwd = (2192 + 16) * 256 + 8 * 32
+    assert [L.swnerf_packed_bwd_floats_kind(k) for k in (0, 1, 2, 3)] == [bwd, bwd + 128 * 256, (1792 + 16) * 256 + 24 * 32, 0]
+    assert L.swnerf_packed_bwd_floats() == bwd and L.swnerf_act_floats_per_row() == 2432
+    assert [L.swnerf_mask_floats(m) for m in (0, 1, 32, 33, 786432)] == [0, 2304, 2304, 4608, 786432 // 32 * 2304]
+    assert L.swnerf_pack_net_bwd_kind(5, None, 10, 4, None, None) == -1
+    assert L.swnerf_mlp_forward_train(None, None, 4, 10, 4, None, None, None, None) == -1
+    assert L.swnerf_mlp_backward_dx(None, None, None, 4, None, None) == -1
+    assert L.swnerf_mlp_backward_dx_pts(None, None, None, None, 4, 10, None, None, None) == -1
+    assert L.swnerf_deform_forward_train(None, None, None, 4, 10, 4, 10, None, None, None, None) == -1
+    assert L.swnerf_deform_backward_dx(None, None, None, 4, None, None) == -1 and b"NULL" in L.swnerf_last_error()
+    assert L.swnerf_gemm_tn(None, 4, 1, None, 4, 1, 8, None, 4, None, None) == -1
 
 
 def test_no_cpu_fallback(built):
