@@ -8,6 +8,7 @@ ray, sampling -> encoding -> MLP -> compositing -> resampling without touching H
 get_embedder encoders; otherwise it runs the reference's op sequence on the individual HIP
 ops (embed / mlp_forward / raw2outputs / sample_pdf)."""
 import inspect
+import os
 import time
 
 import numpy as np
@@ -15,7 +16,8 @@ import torch
 
 from . import _lib
 from .ray import get_rays, ndc_rays, sample_pdf, raw2outputs, _device_of
-from .embedder import EmbedFn
+from .embedder import EmbedFn, to8b
+from .png import write_png
 from .model import vallina_NeRF, NeRFOriginal, DirectTemporalNeRF
 
 DEBUG = False
@@ -297,15 +299,15 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
 
 
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
-    """nerf/run.py:172-219 (image files are the caller's business: `savedir` is not supported here)."""
+    """nerf/run.py:172-219; with `savedir` every frame is also written as '{:03d}.png' of to8b(rgb) (:210-213)."""
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
-    if savedir is not None:
-        raise NotImplementedError("swnerf.render_path: writing PNGs is outside the render path (SURVEY.md 8f rank 3)")
     rgbs, disps = [], []
-    for c2w in render_poses:
+    for i, c2w in enumerate(render_poses):
         rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
         rgbs.append(rgb.cpu().numpy())
         disps.append(disp.cpu().numpy())
+        if savedir is not None:
+            write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
     return np.stack(rgbs, 0), np.stack(disps, 0)

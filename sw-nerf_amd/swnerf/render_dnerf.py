@@ -1,10 +1,14 @@
 """Counterparts of the render functions of the reference's D-NeRF runner
 (d_nerf/run_dnerf.py:24-235, 354-480): batchify, run_network, batchify_rays, render,
 render_rays with the frame_time plumbing.  Same fused dispatch as swnerf.render."""
+import os
+
 import numpy as np
 import torch
 
 from . import _lib
+from .embedder import to8b
+from .png import write_png
 from .ray import get_rays, sample_pdf, raw2outputs
 from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coarse_z
 from .model import DirectTemporalNeRF
@@ -176,3 +180,29 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']
     return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+def render_path(render_poses, render_times, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0,
+                save_also_gt=False, i_offset=0):
+    """d_nerf/run_dnerf.py:175-235: one frame per (pose, time); with `savedir` the frames go to
+    savedir/estim/'{:03d}.png' (and the ground truth to savedir/gt/ when save_also_gt)."""
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    if savedir is not None:
+        save_dir_estim, save_dir_gt = os.path.join(savedir, "estim"), os.path.join(savedir, "gt")
+        os.makedirs(save_dir_estim, exist_ok=True)
+        if save_also_gt:
+            os.makedirs(save_dir_gt, exist_ok=True)
+    rgbs, disps = [], []
+    for i, (c2w, frame_time) in enumerate(zip(render_poses, render_times)):
+        rgb, disp, acc, _ = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], frame_time=frame_time, **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if savedir is not None:
+            write_png(os.path.join(save_dir_estim, '{:03d}.png'.format(i + i_offset)), to8b(rgbs[-1]))
+            if save_also_gt:
+                gt = gt_imgs[i]
+                gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
+                write_png(os.path.join(save_dir_gt, '{:03d}.png'.format(i + i_offset)), to8b(gt))
+    return np.stack(rgbs, 0), np.stack(disps, 0)

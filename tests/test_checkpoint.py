@@ -73,3 +73,23 @@ def test_checkpoint_written_by_the_reference_classes_loads(tmp_path):
     ours = model.DirectTemporalNeRF(D=8, W=256, input_ch=63, input_ch_views=27, input_ch_time=21, skips=[4], use_viewdirs=True)
     assert checkpoint.load_checkpoint(str(path), ours) == 800000
     assert all(np.array_equal(ours.state_dict()[k].numpy(), v) for k, v in cases.weights_dnerf().items())
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """The output side of render_path (nerf/run.py:210-213): to8b + PNG, decoded back with PIL."""
+    import numpy as np
+    from PIL import Image
+    from swnerf.png import write_png
+    from swnerf.embedder import to8b
+    rng = np.random.default_rng(3)
+    for shape in ((17, 23, 3), (5, 7, 4), (9, 4), (1, 1, 3), (6, 6, 1)):
+        img = to8b(rng.uniform(-0.2, 1.2, shape).astype(np.float32))
+        p = str(tmp_path / ("x%d.png" % len(shape) + str(shape[0])))
+        write_png(p, img)
+        back = np.asarray(Image.open(p))
+        assert np.array_equal(back, img[..., 0] if (img.ndim == 3 and img.shape[2] == 1) else img), shape
+    import pytest
+    with pytest.raises(TypeError):
+        write_png(str(tmp_path / "f.png"), np.zeros((2, 2, 3), np.float32))
+    with pytest.raises(ValueError):
+        write_png(str(tmp_path / "g.png"), np.zeros((2, 2, 5), np.uint8))

@@ -351,6 +351,37 @@ def test_render_full_image_c2w_and_chunking(sw, dev, nets):
     close(a[3]["rgb0"].reshape(-1, 3), ref["rgb0"], what="render(c2w) rgb0", **RGB_TOL)
 
 
+def test_render_path_writes_frames(sw, dev, nets, tmp_path):
+    """render_path (nerf/run.py:172-219, d_nerf/run_dnerf.py:175-235): stacked frames == render() per pose, and with
+    `savedir` the PNG of every frame decodes to to8b(rgb) (the reference writes them with imageio)."""
+    from PIL import Image
+    H, W = 20, 28
+    poses = [T(cases.synth.lego_camera(H, W, theta=th)[1]).to(dev) for th in (0.0, 40.0)]
+    K = cases.synth.lego_camera(H, W)[0]
+    kw = dict(ndc=False, near=2., far=6., use_viewdirs=True, network_fn=nets["coarse"], network_query_fn=_query(sw),
+              N_samples=64, N_importance=128, network_fine=nets["fine"], white_bkgd=True, perturb=0., raw_noise_std=0.)
+    d = tmp_path / "static"
+    d.mkdir()
+    rgbs, disps = sw.render.render_path(poses, (H, W, float(K[0, 0])), K, 1024 * 32, kw, savedir=str(d))
+    assert rgbs.shape == (2, H, W, 3) and disps.shape == (2, H, W)
+    one = sw.render.render(H, W, K, chunk=1024 * 32, c2w=poses[1][:3, :4], **kw)[0]
+    assert np.array_equal(rgbs[1], one.cpu().numpy())
+    for i in range(2):
+        assert np.array_equal(np.asarray(Image.open(str(d / f"{i:03d}.png"))), sw.ray.to8b(rgbs[i]))
+    half, _ = sw.render.render_path(poses[:1], (H, W, float(K[0, 0])), K, 1024 * 32, kw, render_factor=2)
+    assert half.shape == (1, H // 2, W // 2, 3)
+    # D-NeRF: one time per pose, estim/ (+ gt/) sub-directories, i_offset
+    kwd = dict(ndc=False, near=2., far=6., use_viewdirs=True, network_fn=nets["dn"], network_query_fn=_query_d(sw),
+               N_samples=64, N_importance=128, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    gt = np.random.default_rng(1).uniform(0, 1, (2, H, W, 3)).astype(np.float32)
+    r2, _ = sw.render_dnerf.render_path(poses, [0.0, 0.5], (H, W, float(K[0, 0])), 1024 * 32, kwd, gt_imgs=gt,
+                                        savedir=str(tmp_path / "dn"), save_also_gt=True, i_offset=7)
+    assert r2.shape == (2, H, W, 3)
+    for i in range(2):
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / "dn" / "estim" / f"{i + 7:03d}.png"))), sw.ray.to8b(r2[i]))
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / "dn" / "gt" / f"{i + 7:03d}.png"))), sw.ray.to8b(gt[i]))
+
+
 def test_fused_equals_unfused(sw, dev, nets):
     """The fused pass and the op-by-op path (embed -> mlp_forward -> raw2outputs -> sample_pdf) agree."""
     g = cases.g7_inputs(n=128, seed=21)
