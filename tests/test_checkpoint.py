@@ -93,3 +93,58 @@ def test_png_writer_roundtrip(tmp_path):
         write_png(str(tmp_path / "f.png"), np.zeros((2, 2, 3), np.float32))
     with pytest.raises(ValueError):
         write_png(str(tmp_path / "g.png"), np.zeros((2, 2, 5), np.uint8))
+
+
+def _args(tmp_path, **over):
+    """The options create_nerf reads, at the values of the shipped lego / bouncingballs configs
+    (nerf/configs/lego.txt, d_nerf/configs/bouncingballs.txt; defaults of utils.py:20-100)."""
+    from types import SimpleNamespace
+    a = dict(expname="exp", basedir=str(tmp_path), netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, lrate=5e-4,
+             netchunk=1024 * 64, no_reload=False, ft_path=None, N_samples=64, N_importance=128, perturb=1., use_viewdirs=True,
+             i_embed=0, multires=10, multires_views=4, raw_noise_std=0., dataset_type="blender", white_bkgd=True, no_ndc=False,
+             lindisp=False, nerf_type="direct_temporal", not_zero_canonical=False, use_two_models_for_fine=False,
+             do_half_precision=False)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def test_create_nerf_mirrors_the_runners(tmp_path):
+    """nerf/run.py:222-313 and d_nerf/run_dnerf.py:238-352: same return tuple, same render_kwargs keys, the closure is
+    recognised by the fused dispatch, checkpoints written in the reference's format are reloaded."""
+    import torch
+    from swnerf import runner, render, model, checkpoint
+    args = _args(tmp_path)
+    train, test, start, grad_vars, opt = runner.create_nerf(args, device="cpu")
+    assert start == 0 and isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 5e-4 and opt.defaults["betas"] == (0.9, 0.999)
+    assert list(train.keys()) == ["network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                                  "use_viewdirs", "white_bkgd", "raw_noise_std", "ndc", "lindisp"]      # run.py:283-299
+    assert test["perturb"] is False and test["raw_noise_std"] == 0. and train["perturb"] == 1.
+    assert isinstance(train["network_fn"], model.vallina_NeRF) and isinstance(train["network_fine"], model.vallina_NeRF)
+    assert train["network_fn"].input_ch == 63 and train["network_fn"].input_ch_views == 27
+    assert len(grad_vars) == 48 and sum(p.numel() for p in grad_vars) == 2 * 595844
+    with torch.no_grad():
+        assert render.fused_plan(train["network_query_fn"], [train["network_fn"], train["network_fine"]]) == (10, 4, 0)
+    llff = runner.create_nerf(_args(tmp_path, dataset_type="llff", N_importance=0), device="cpu")
+    assert "ndc" not in llff[0] and llff[0]["network_fine"] is None and len(llff[3]) == 24                # run.py:296
+    # reload: newest *.tar of basedir/expname (run.py:261-280)
+    with torch.no_grad():
+        for p in grad_vars:
+            p.add_(0.25)
+    checkpoint.save_checkpoint(str(tmp_path), "exp", 1000, 1001, train["network_fn"], train["network_fine"], opt)
+    t2, _, start2, gv2, _ = runner.create_nerf(args, device="cpu")
+    assert start2 == 1001 and all(torch.equal(a, b) for a, b in zip(gv2, grad_vars))
+    assert runner.create_nerf(_args(tmp_path, no_reload=True), device="cpu")[2] == 0
+    # D-NeRF
+    dargs = _args(tmp_path, expname="dn")
+    tr, te, st, gv, op = runner.create_dnerf(dargs, device="cpu")
+    assert isinstance(tr["network_fn"], model.DirectTemporalNeRF) and tr["network_fine"] is None and st == 0
+    assert list(tr.keys())[:10] == ["network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                                    "use_viewdirs", "white_bkgd", "raw_noise_std", "use_two_models_for_fine"]
+    assert tr["network_fn"].input_ch_time == 21 and tr["network_fn"].zero_canonical and len(gv) == 42
+    with torch.no_grad():
+        assert render.fused_plan(tr["network_query_fn"], [tr["network_fn"], None], need_time=True) == (10, 4, 10)
+    two = runner.create_dnerf(_args(tmp_path, expname="dn2", use_two_models_for_fine=True, not_zero_canonical=True), device="cpu")
+    assert isinstance(two[0]["network_fine"], model.DirectTemporalNeRF) and not two[0]["network_fn"].zero_canonical
+    import pytest
+    with pytest.raises(NotImplementedError):
+        runner.create_dnerf(_args(tmp_path, do_half_precision=True), device="cpu")

@@ -278,3 +278,40 @@ def test_gemm_tn_256x256_dma_path(dev, M):
     assert torch.equal(C[:, :63], C0[:, :63])
     bref = A[:, 512:768].double().sum(0)
     assert float((bias - bref.float()).abs().max()) <= 2e-5 * float(bref.abs().max())
+
+
+def test_training_loop_through_create_nerf(dev, tmp_path):
+    """The core of train() (nerf/run.py:635-735) on the build: create_nerf -> render(**render_kwargs_train) -> img2mse on
+    rgb and rgb0 -> backward -> Adam step -> exponential lr decay -> checkpoint.  The loss on a fixed batch must fall."""
+    from types import SimpleNamespace
+    import swnerf.render as render, swnerf.runner as runner, swnerf.checkpoint as checkpoint
+    args = SimpleNamespace(expname="loop", basedir=str(tmp_path), netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                           lrate=5e-4, lrate_decay=500, netchunk=1024 * 64, no_reload=False, ft_path=None, N_samples=64,
+                           N_importance=128, perturb=1., use_viewdirs=True, i_embed=0, multires=10, multires_views=4,
+                           raw_noise_std=0., dataset_type="blender", white_bkgd=True, no_ndc=False, lindisp=False)
+    torch.manual_seed(0)
+    train_kw, test_kw, start, grad_vars, optimizer = runner.create_nerf(args, device=dev)
+    g = cases.g7_inputs(n=256, seed=11)
+    rays = (T(g["rays_o"]).to(dev), T(g["rays_d"]).to(dev))
+    target = T(np.random.default_rng(2).uniform(0, 1, (256, 3)).astype(np.float32)).to(dev)
+    K = cases.synth.lego_camera(400, 400)[0]
+    img2mse = lambda x, y: torch.mean((x - y) ** 2)
+    losses = []
+    for i in range(start, start + 25):
+        rgb, disp, acc, extras = render.render(400, 400, K, chunk=1024 * 32, rays=rays, near=2., far=6., **train_kw)
+        optimizer.zero_grad()
+        loss = img2mse(rgb, target) + img2mse(extras['rgb0'], target)
+        loss.backward()
+        optimizer.step()
+        new_lrate = args.lrate * (0.1 ** ((i + 1) / (args.lrate_decay * 1000)))                  # run.py:704-708
+        for pg in optimizer.param_groups:
+            pg['lr'] = new_lrate
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+    path = checkpoint.save_checkpoint(args.basedir, args.expname, 25, 25, train_kw['network_fn'], train_kw['network_fine'], optimizer)
+    _, test2, start2, _, _ = runner.create_nerf(args, device=dev)
+    assert start2 == 25 and path.endswith("000025.tar")
+    with torch.no_grad():                                                                         # the reloaded nets render the same
+        a = render.render(400, 400, K, chunk=1024 * 32, rays=rays, near=2., far=6., **test_kw)[0]
+        b = render.render(400, 400, K, chunk=1024 * 32, rays=rays, near=2., far=6., **test2)[0]
+    assert torch.equal(a, b)
