@@ -43,7 +43,12 @@ def run_network(inputs, viewdirs, frame_time, fn, embed_fn, embeddirs_fn, embedt
     if viewdirs is not None:
         input_dirs_flat = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, viewdirs.shape[-1]])
         embedded = torch.cat([embedded, embeddirs_fn(input_dirs_flat)], -1)
-    outputs_flat, dx_flat = batchify(fn, netchunk)(embedded, [embedded_time, embedded_time])
+    if isinstance(fn, DirectTemporalNeRF) and fn._wants_grad():
+        # training: `netchunk` only bounds the reference's activation memory; one call lets the weight-gradient GEMMs run
+        # over all rows at once (same reasoning as swnerf.render.run_network).  Results are identical either way.
+        outputs_flat, dx_flat = fn(embedded, [embedded_time, embedded_time])
+    else:
+        outputs_flat, dx_flat = batchify(fn, netchunk)(embedded, [embedded_time, embedded_time])
     outputs = torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
     return outputs, torch.reshape(dx_flat, list(inputs.shape[:-1]) + [dx_flat.shape[-1]])
 
