@@ -123,7 +123,22 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
     near, far, frame_time = bounds[..., 0], bounds[..., 1], bounds[..., 2]
     z_samples = None
     rgb_map_0 = disp_map_0 = acc_map_0 = position_delta_0 = None
-    if z_vals is None:
+    fused_coarse = None
+    if z_vals is None and N_importance > 0 and not use_two_models_for_fine and ray_batch.shape[-1] == 12:
+        # The coarse pass of the one-model configuration only feeds the resampling and runs under no_grad in the
+        # reference (run_dnerf.py:417-421): even in a training step it can be the fused HIP pass.
+        with torch.no_grad():
+            if fused_plan(network_query_fn, [network_fn], need_time=True) is not None:
+                t0 = _single_time(ray_batch)
+                deform = isinstance(network_fn, DirectTemporalNeRF) and not (t0 == 0. and network_fn.zero_canonical)
+                t_rand, u, noise = _rng_inputs(N_rays, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
+                fused_coarse = render_pass(ray_batch.detach(), network_fn, N_samples, lindisp=lindisp, t_rand=t_rand,
+                                           noise=noise(N_samples), white_bkgd=white_bkgd, want=[], n_importance=N_importance,
+                                           u=u, run_deform=deform)
+    z_std = None
+    if fused_coarse is not None:
+        z_vals, z_std = fused_coarse["z_fine"], fused_coarse["z_std"]
+    elif z_vals is None:
         z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
         if N_importance > 0:
@@ -150,6 +165,8 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
                 ret[k] = v
         if z_samples is not None:
             ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
+        elif z_std is not None:
+            ret['z_std'] = z_std
     return ret
 
 
