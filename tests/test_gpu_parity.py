@@ -403,7 +403,7 @@ def test_render_rays_ragged_and_edges(sw, dev, nets):
     q = _query(sw)
     sd_c, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
     g = cases.g7_inputs(n=37, seed=33)
-    for (S, Ni) in ((40, 24), (33, 95), (64, 0), (7, 5)):
+    for (S, Ni) in ((40, 24), (33, 95), (64, 0), (7, 5), (50, 51), (64, 37), (100, 0)):     # fine pass: 64, 128, -, 12, 101, 101 samples
         r = sw.render.render_rays(_rb(g, dev), nets["coarse"], q, S, N_importance=Ni, network_fine=nets["fine"], white_bkgd=True)
         ref = O.render_rays(_rb(g, "cpu"), sd_c, sd_f, S, Ni, white_bkgd=True)
         _cmp(r, ref, list(r.keys()), f"S={S} Ni={Ni}", resampled=Ni > 0)
