@@ -138,6 +138,14 @@ int swnerf_mlp_backward_dx(const float* packed_bwd, const float* bits, const flo
                            float* grad, void* stream);
 int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
                    float* C, int ldc, float* bias, void* stream);
+/* gemm_tn for a 256 x 256 block (No = Ni = 256) with up to two riders that share one of its operands and its pass
+ * over the rows (each may be NULL):
+ *   B2 [M, Ni2 <= 64]:  C2[256, ldc2] += A^T . B2            (the gamma(x) columns of a skip layer: same A)
+ *   A2 [M, No2 <= 32]:  C3[No2, ldc3] += A2^T . B,  bias3[No2] += column sums of A2   (alpha_linear: same B as feature_linear)
+ * Equivalent to the corresponding separate swnerf_gemm_tn calls (which it falls back to for small or unaligned M). */
+int swnerf_gemm_tn_fused(const float* A, int lda, const float* B, int ldb, int64_t M, float* C, int ldc, float* bias,
+                         const float* B2, int ldb2, int Ni2, float* C2, int ldc2,
+                         const float* A2, int lda2, int No2, float* C3, int ldc3, float* bias3, void* stream);
 
 /* ---- training path of DirectTemporalNeRF (autograd of model.py:128-151; the loss of
  * d_nerf/run_dnerf.py:690-725 needs d/d(position_delta) too).  The forward is the composition the

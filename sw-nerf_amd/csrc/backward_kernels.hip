@@ -273,8 +273,27 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
 // 4 LDS reads per 4 MFMAs.
 #define GD_SLAB 32
 #define GD_BUF_FLOATS (2 * GD_SLAB * 256)            // A slab then B slab
-__global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
-    extern __shared__ __attribute__((aligned(16))) float gd_lds[];           // [2][GD_BUF_FLOATS]
+#define GD_B2_FLOATS (GD_SLAB * 64)                  // optional second B operand, <= 64 columns
+#define GD_A2_FLOATS (GD_SLAB * 32)                  // optional second A operand, <= 32 columns (zero padded)
+// Two optional riders on the same pass (each one extra accumulator tile per wave):
+//   B2 [M, Ni2 <= 64]:  C2[256, Ni2] += A^T . B2   - the gamma(x) columns of the skip layer, whose dW shares A = d pre_5
+//                       with the 256-wide part (cat[gamma(x), h4], model.py:45-46)
+//   A2 [M, No2 <= 32]:  C3[No2, 256] += A2^T . B, bias3 += column sums of A2   - alpha_linear, which shares B = h7 with
+//                       feature_linear
+// Their slabs are small and unaligned (ld 90, ld 4): staged through registers by plain loads issued at the top of the
+// compute phase and written to LDS behind it, double buffered like the DMA slabs.
+struct GemmFused {
+    GemmTN g;
+    const float* B2; int ldb2; int Ni2; float* C2; int ldc2;
+    const float* A2; int lda2; int No2; float* C3; int ldc3; float* bias3;
+};
+
+template <bool HB2, bool HA2>
+__global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) {
+    const GemmTN& P = F.g;
+    extern __shared__ __attribute__((aligned(16))) float gd_lds[];           // [2][GD_BUF_FLOATS] [2][B2] [2][A2]
+    float* b2s = gd_lds + 2 * GD_BUF_FLOATS;
+    float* a2s = b2s + (HB2 ? 2 * GD_B2_FLOATS : 0);
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int o0 = 64 * (w & 3), i0 = 64 * (w >> 2);
@@ -309,32 +328,79 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
             cur[q] += step[q];
         }
     };
-    f32x16 acc[4];
+    // rider slabs: element e of the B2 slab is (row e>>6, col e&63), of the A2 slab (row e>>5, col e&31); loads are
+    // unconditional (clamped), the zero fill happens at the LDS write
+    float rb2[2] = {0.f, 0.f}, ra2 = 0.f;
+    auto rider_load = [&](int sl) {
+        if (HB2) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+            for (int k = 0; k < 2; ++k) {
+                const int e = t + 1024 * k, row = e >> 6, col = e & 63;
+                rb2[k] = F.B2[(m0 + min(sl * GD_SLAB + row, mlen - 1)) * F.ldb2 + (col < F.Ni2 ? col : 0)];
+            }
+        }
+        if (HA2) {
+            const int row = t >> 5, col = t & 31;
+            ra2 = F.A2[(m0 + min(sl * GD_SLAB + row, mlen - 1)) * F.lda2 + (col < F.No2 ? col : 0)];
+        }
+    };
+    auto rider_store = [&](int sl) {
+        if (HB2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    float bs0 = 0.f, bs1 = 0.f;
+            for (int k = 0; k < 2; ++k) {
+                const int e = t + 1024 * k, col = e & 63;
+                b2s[(sl & 1) * GD_B2_FLOATS + e] = (col < F.Ni2) ? rb2[k] : 0.f;
+            }
+        }
+        if (HA2) {
+            const int row = t >> 5, col = t & 31;
+            a2s[(sl & 1) * GD_A2_FLOATS + t] = (col < F.No2 && sl * GD_SLAB + row < mlen) ? ra2 : 0.f;
+        }
+    };
+    f32x16 acc[4], accb, acca;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accb[r] = 0.f; acca[r] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b][r] = 0.f;
+    }
+    float bs0 = 0.f, bs1 = 0.f, bs3 = 0.f;
+    const int ot2 = 32 * (w & 7), it2 = 32 * (w >> 3);       // B2 rider: this wave's 32 x 32 tile of C2
     issue(0);
+    if (HB2 || HA2) { rider_load(0); rider_store(0); }
 #pragma nounroll
     for (int sl = 0; sl < nslab; ++sl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        const float* As = gd_lds + (sl & 1) * GD_BUF_FLOATS + o0 + i;
-        const float* Bs = gd_lds + (sl & 1) * GD_BUF_FLOATS + GD_SLAB * 256 + i0 + i;
+        const float* Ab = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+        const float* As = Ab + o0 + i;
+        const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
         const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
         // operands of k-pair s+1 are read while the MFMAs of k-pair s run; the first reads go out BEFORE the next
         // slab's DMA is issued, so that its scalar address work hides under their LDS latency
         float a0 = As[hp * 256], a1 = As[hp * 256 + 32], b0 = Bs[hp * 256], b1 = Bs[hp * 256 + 32];
         __builtin_amdgcn_sched_barrier(0);
-        if (sl + 1 < nslab) issue(sl + 1);
-#pragma unroll
+        if (sl + 1 < nslab) {
+            issue(sl + 1);
+            if (HB2 || HA2) rider_load(sl + 1);
+        }
+        constexpr int UNR = (HB2 || HA2) ? 4 : GD_SLAB / 2;    // a rider's extra tile leaves no registers for a full unroll
+#pragma unroll UNR
         for (int s = 0; s < GD_SLAB / 2; ++s) {
             const int row = 2 * s + hp;
             const bool ok = row < valid;                      // one code path: two selects per 4 MFMAs
             const float c0 = ok ? a0 : 0.f, c1 = ok ? a1 : 0.f, d0 = b0, d1 = b1;
-            if (s + 1 < GD_SLAB / 2) {
-                const int nr = (row + 2) * 256;
+            float e0 = 0.f, e1 = 0.f, f0 = 0.f, f1 = 0.f;
+            if (HB2) {                                        // A columns of this wave's C2 tile x B2 columns
+                e0 = Ab[row * 256 + ot2 + i]; e0 = ok ? e0 : 0.f;
+                e1 = b2s[(sl & 1) * GD_B2_FLOATS + row * 64 + it2 + i];
+            }
+            if (HA2) {                                        // A2 columns (zero padded) x B columns 32(w&7).. (waves 8..15
+                f0 = a2s[(sl & 1) * GD_A2_FLOATS + row * 32 + i];      // duplicate 0..7 rather than branch; only 0..7 write)
+                f1 = Ab[GD_SLAB * 256 + row * 256 + 32 * (w & 7) + i];
+            }
+            {                                                 // (the last iteration reads 2 rows past the slab: the next
+                const int nr = (min(row + 2, GD_SLAB - 1)) * 256;   // buffer region or its own last row - harmless, unused)
                 a0 = As[nr]; a1 = As[nr + 32]; b0 = Bs[nr]; b1 = Bs[nr + 32];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -343,8 +409,11 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d0, acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d1, acc[3], 0, 0, 0);
+            if (HB2) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, e1, accb, 0, 0, 0);
+            if (HA2) { acca = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, f1, acca, 0, 0, 0); bs3 += f0; }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if ((HB2 || HA2) && sl + 1 < nslab) rider_store(sl + 1);   // visible after the next barrier
     }
     // C/D map: register r of lane (j = i, h = hp) of tile (oa, ib) is row o0 + 32 oa + frow(r,h), column i0 + 32 ib + j
 #pragma unroll
@@ -360,6 +429,69 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmTN P) {
         bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
         if (hp == 0) { atomicAdd(P.bias + o0 + i, bs0); atomicAdd(P.bias + o0 + 32 + i, bs1); }
     }
+    if (HB2 && it2 + i < F.Ni2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(F.C2 + (size_t)(ot2 + sw_frow(r, hp)) * F.ldc2 + it2 + i, accb[r]);
+    }
+    if (HA2 && w < 8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (sw_frow(r, hp) < F.No2) atomicAdd(F.C3 + (size_t)sw_frow(r, hp) * F.ldc3 + 32 * w + i, acca[r]);
+        if (F.bias3 && w == 0) {
+            bs3 += __shfl_xor(bs3, 32, 64);
+            if (hp == 0 && i < F.No2) atomicAdd(F.bias3 + i, bs3);
+        }
+    }
+}
+
+static int gemm_dma_launch(const GemmFused& F0, void* stream) {
+    GemmFused F = F0;
+    const int64_t M = F.g.M;
+    int64_t nwg = 256;                                   // one workgroup per CU-sized row slice, whole slabs
+    int64_t rows = ((M + nwg - 1) / nwg + GD_SLAB - 1) / GD_SLAB * GD_SLAB;
+    nwg = (M + rows - 1) / rows;
+    F.g.rows_per_wg = rows;
+    const bool hb2 = F.B2 != nullptr, ha2 = F.A2 != nullptr;
+    const size_t lds = (2 * GD_BUF_FLOATS + (hb2 ? 2 * GD_B2_FLOATS : 0) + (ha2 ? 2 * GD_A2_FLOATS : 0)) * sizeof(float);
+    const dim3 grid((unsigned)nwg), block(1024);
+    hipStream_t st = (hipStream_t)stream;
+    if (hb2 && ha2) return sw_fail(SWNERF_E_ARG, "gemm_tn (dma): one rider per launch");
+    else if (hb2) hipLaunchKernelGGL((gemm_tn_dma_kernel<true, false>), grid, block, lds, st, F);
+    else if (ha2) hipLaunchKernelGGL((gemm_tn_dma_kernel<false, true>), grid, block, lds, st, F);
+    else hipLaunchKernelGGL((gemm_tn_dma_kernel<false, false>), grid, block, lds, st, F);
+    return sw_check(hipGetLastError(), "gemm_tn (dma) launch");
+}
+
+extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
+                              float* C, int ldc, float* bias, void* stream);
+
+// The 256 x 256 GEMM with riders (see gemm_tn_dma_kernel).  Falls back to separate swnerf_gemm_tn calls when the
+// main operands do not qualify for the DMA kernel (alignment, M < 4096).
+extern "C" int swnerf_gemm_tn_fused(const float* A, int lda, const float* B, int ldb, int64_t M, float* C, int ldc, float* bias,
+                                    const float* B2, int ldb2, int Ni2, float* C2, int ldc2,
+                                    const float* A2, int lda2, int No2, float* C3, int ldc3, float* bias3, void* stream) {
+    if (M == 0) return 0;
+    if (!A || !B || !C || M < 0 || lda < 256 || ldb < 256 || ldc < 256)
+        return sw_fail(SWNERF_E_ARG, "gemm_tn_fused: bad main operands (M=%lld lda=%d ldb=%d ldc=%d)", (long long)M, lda, ldb, ldc);
+    if (B2 && (!C2 || Ni2 < 1 || Ni2 > 64 || ldb2 < Ni2 || ldc2 < Ni2)) return sw_fail(SWNERF_E_ARG, "gemm_tn_fused: bad B2 rider (Ni2=%d)", Ni2);
+    if (A2 && (!C3 || No2 < 1 || No2 > 32 || lda2 < No2 || ldc3 < 256)) return sw_fail(SWNERF_E_ARG, "gemm_tn_fused: bad A2 rider (No2=%d)", No2);
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
+    if (aligned && M >= 4096) {
+        GemmFused F;
+        F.g.A = A; F.g.lda = lda; F.g.No = 256; F.g.B = B; F.g.ldb = ldb; F.g.Ni = 256; F.g.C = C; F.g.ldc = ldc; F.g.bias = bias; F.g.M = M;
+        F.B2 = B2; F.ldb2 = ldb2; F.Ni2 = Ni2; F.C2 = C2; F.ldc2 = ldc2;
+        F.A2 = A2; F.lda2 = lda2; F.No2 = No2; F.C3 = C3; F.ldc3 = ldc3; F.bias3 = bias3;
+        if (B2 && A2) {                                  // one rider per launch: A2 goes on its own
+            F.A2 = nullptr;
+            int rc2 = swnerf_gemm_tn(A2, lda2, No2, B, ldb, 256, M, C3, ldc3, bias3, stream);
+            if (rc2) return rc2;
+        }
+        return gemm_dma_launch(F, stream);
+    }
+    int rc = swnerf_gemm_tn(A, lda, 256, B, ldb, 256, M, C, ldc, bias, stream);
+    if (!rc && B2) rc = swnerf_gemm_tn(A, lda, 256, B2, ldb2, Ni2, M, C2, ldc2, nullptr, stream);
+    if (!rc && A2) rc = swnerf_gemm_tn(A2, lda2, No2, B, ldb, 256, M, C3, ldc3, bias3, stream);
+    return rc;
 }
 
 extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,
@@ -371,13 +503,11 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
     P.A = A; P.lda = lda; P.No = No; P.B = B; P.ldb = ldb; P.Ni = Ni; P.C = C; P.ldc = ldc; P.bias = bias; P.M = M;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
     if (aligned && No == 256 && Ni == 256 && M >= 4096) {
-        // one workgroup per CU-sized row slice, whole slabs
-        int64_t nwg = 256;
-        int64_t rows = ((M + nwg - 1) / nwg + GD_SLAB - 1) / GD_SLAB * GD_SLAB;
-        nwg = (M + rows - 1) / rows;
-        P.rows_per_wg = rows;
-        hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)nwg), dim3(1024), 2 * GD_BUF_FLOATS * sizeof(float), (hipStream_t)stream, P);
-        return sw_check(hipGetLastError(), "gemm_tn (dma) launch");
+        GemmFused F;
+        F.g = P;
+        F.B2 = nullptr; F.ldb2 = 0; F.Ni2 = 0; F.C2 = nullptr; F.ldc2 = 0;
+        F.A2 = nullptr; F.lda2 = 0; F.No2 = 0; F.C3 = nullptr; F.ldc3 = 0; F.bias3 = nullptr;
+        return gemm_dma_launch(F, stream);
     }
     // split the rows over ~2 workgroups per CU, at least 256 rows each (whole slabs)
     int64_t nwg = (M + 255) / 256;

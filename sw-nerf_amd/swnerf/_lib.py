@@ -14,7 +14,7 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
-           "swnerf_mlp_backward_dx", "swnerf_gemm_tn",
+           "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx"]
 BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM = 0, 1, 2
@@ -81,6 +81,9 @@ def lib():
     L.swnerf_pack_net_bwd.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
     L.swnerf_mlp_backward_dx.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     L.swnerf_gemm_tn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]
+    L.swnerf_gemm_tn_fused.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_int, c_int, c_void_p, c_int,
+                                       c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]
     L.swnerf_packed_bwd_floats_kind.restype = c_size_t
     L.swnerf_packed_bwd_floats_kind.argtypes = [c_int]
     L.swnerf_pack_net_bwd_kind.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]

@@ -51,6 +51,16 @@ def _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias):
                                 C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(bias), st), "gemm_tn")
 
 
+def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col=0, Ni2=0, C2=None, c2_col=0,
+                   A2=None, a2_col=0, No2=0, C3=None, bias3=None):
+    """256x256 block C[:, c_col:] += A[:, a_col:]^T . B[:, b_col:] with the riders of swnerf_gemm_tn_fused."""
+    off = lambda T_, col: None if T_ is None else T_.data_ptr() + 4 * col
+    ld = lambda T_: 0 if T_ is None else T_.stride(0)
+    _lib.check(L.swnerf_gemm_tn_fused(off(A, a_col), ld(A), off(B, b_col), ld(B), M, off(C, c_col), ld(C), _lib.ptr(bias),
+                                      off(B2, b2_col), ld(B2), Ni2, off(C2, c2_col), ld(C2),
+                                      off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3), st), "gemm_tn_fused")
+
+
 def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
     """dW / db of the 12 Linear layers of the canonical net (g: zeroed fp32 tensors in _CANON_ORDER) from the
     dX chain's `grad`, the saved `act`, the embedded inputs x = [gamma(x) | gamma(d)] and d raw."""
@@ -59,12 +69,12 @@ def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
     mm(grad, 0, 256, x, 0, Cpos, 0, 0, True)                                   # pts_linears.0
     for l in (1, 2, 3, 4, 6, 7):
         mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, 2 * l, 0, True)
-    mm(grad, 1280, 256, x, 0, Cpos, 10, 0, True)                               # pts_linears.5 = [pts | h4]
-    mm(grad, 1280, 256, act, 1024, 256, 10, Cpos, False)
+    # pts_linears.5 = [pts | h4]: one pass over d pre_5 for both column blocks
+    _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=x, b2_col=0, Ni2=Cpos, C2=g[10], c2_col=0)
     mm(grad, 2304, 128, act, 2048, 256, 16, 0, True)                           # views_linears.0 = [feature | dirs]
     mm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
-    mm(grad, 2048, 256, act, 1792, 256, 18, 0, True)                           # feature_linear
-    mm(d_out, 3, 1, act, 1792, 256, 20, 0, True)                               # alpha_linear
+    # feature_linear, and alpha_linear riding on its pass over h7
+    _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
     mm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
 
 
@@ -170,8 +180,8 @@ class _DnerfTrain(torch.autograd.Function):
         mm(grad_d, 0, 256, t_emb, 0, Ct, 0, Cpos, False)
         for l in (1, 2, 3, 4, 6, 7):
             mm(grad_d, 256 * l, 256, act_d, 256 * (l - 1), 256, 2 * l, 0, True)
-        mm(grad_d, 1280, 256, x, 0, Cpos, 10, 0, True)                           # _time.5 = [gamma(x) | h4]
-        mm(grad_d, 1280, 256, act_d, 1024, 256, 10, Cpos, False)
+        _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=x, b2_col=0, Ni2=Cpos, C2=gd[10],
+                       c2_col=0)                                                 # _time.5 = [gamma(x) | h4]
         mm(g_dx, 0, 3, act_d, 1792, 256, 16, 0, True)                            # _time_out
         return (None, None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 

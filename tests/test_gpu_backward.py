@@ -315,3 +315,44 @@ def test_training_loop_through_create_nerf(dev, tmp_path):
         a = render.render(400, 400, K, chunk=1024 * 32, rays=rays, near=2., far=6., **test_kw)[0]
         b = render.render(400, 400, K, chunk=1024 * 32, rays=rays, near=2., far=6., **test2)[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [4096, 70000 + 13, 300])
+def test_gemm_tn_fused_riders(dev, M):
+    """swnerf_gemm_tn_fused against torch in float64: the B2 rider (63 columns of an unaligned [M,90] operand into a
+    column window of C), the A2 rider (column 3 of an [M,4] operand, with its bias), both together, and the small-M
+    fallback (separate launches)."""
+    from swnerf import _lib, model
+    L = _lib.lib()
+    gen = torch.Generator(device="cpu").manual_seed(7 * M)
+    A = torch.randn((M, 2432), generator=gen).to(dev)
+    B = torch.randn((M, 2432), generator=gen).to(dev)
+    X = torch.randn((M, 90), generator=gen).to(dev)
+    D = torch.randn((M, 4), generator=gen).to(dev)
+    st = _lib.stream_of(A)
+    tol = lambda ref: 2e-5 * float(ref.abs().max())
+    Ad, Bd = A[:, 1280:1536].double(), B[:, 1024:1280].double()
+    # B2 rider
+    C = torch.zeros((256, 319), device=dev)
+    bias = torch.zeros(256, device=dev)
+    model._gemm_tn_fused(L, st, M, A, 1280, B, 1024, C, 63, bias, B2=X, b2_col=0, Ni2=63, C2=C, c2_col=0)
+    ref = torch.cat([Ad.T @ X[:, :63].double(), Ad.T @ Bd], 1)
+    assert float((C - ref.float()).abs().max()) <= tol(ref)
+    assert float((bias - Ad.sum(0).float()).abs().max()) <= 2e-5 * float(Ad.sum(0).abs().max())
+    # A2 rider
+    C = torch.zeros((256, 256), device=dev)
+    C3, b3 = torch.zeros((1, 256), device=dev), torch.zeros(1, device=dev)
+    model._gemm_tn_fused(L, st, M, A, 1280, B, 1024, C, 0, None, A2=D, a2_col=3, No2=1, C3=C3, bias3=b3)
+    assert float((C - (Ad.T @ Bd).float()).abs().max()) <= tol(Ad.T @ Bd)
+    r3 = D[:, 3:4].double().T @ Bd
+    assert float((C3 - r3.float()).abs().max()) <= tol(r3)
+    assert abs(float(b3) - float(D[:, 3].double().sum())) <= 2e-5 * max(1.0, abs(float(D[:, 3].double().sum())))
+    # both at once (3 rows of A2)
+    C = torch.zeros((256, 319), device=dev)
+    C3, b3 = torch.zeros((3, 256), device=dev), torch.zeros(3, device=dev)
+    model._gemm_tn_fused(L, st, M, A, 1280, B, 1024, C, 63, None, B2=X, b2_col=0, Ni2=63, C2=C, c2_col=0,
+                         A2=D, a2_col=0, No2=3, C3=C3, bias3=b3)
+    assert float((C - ref.float()).abs().max()) <= tol(ref)
+    r3 = D[:, :3].double().T @ Bd
+    assert float((C3 - r3.float()).abs().max()) <= tol(r3)
+    assert float((b3 - D[:, :3].double().sum(0).float()).abs().max()) <= 2e-5 * float(D[:, :3].double().sum(0).abs().max() + 1)
