@@ -45,6 +45,17 @@ class _NoBackward(torch.autograd.Function):
             "run the render path under torch.no_grad()")
 
 
+def _zero_grads(params):
+    """fp32 gradient buffers for `params`, views of ONE zeroed allocation (one fill instead of one per tensor).  Every
+    view starts 16-byte aligned, as the GEMM kernels' vector paths want."""
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+
+
 def _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias):
     """C[:, c_col:c_col+Ni] += A[:, a_col:a_col+No]^T . B[:, b_col:b_col+Ni];  bias += column sums of that A block"""
     _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
@@ -111,7 +122,7 @@ class _MlpTrain(torch.autograd.Function):
         st = _lib.stream_of(x)
         _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(bits), _lib.ptr(d_out), M, _lib.ptr(grad), st),
                    "mlp_backward_dx")
-        g = [torch.zeros_like(p, dtype=torch.float32) for p in params]      # order: _CANON_ORDER
+        g = _zero_grads(params)                                               # order: _CANON_ORDER
         _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g)
         return (None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
@@ -167,7 +178,7 @@ class _DnerfTrain(torch.autograd.Function):
         grad_c, d_pts = torch.empty_like(act_c), torch.empty((M, 3), dtype=torch.float32, device=x.device)
         _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(bits_c), _lib.ptr(d_out),
                                                 _lib.ptr(pts2), M, Lp, _lib.ptr(grad_c), _lib.ptr(d_pts), st), "mlp_backward_dx_pts")
-        g = [torch.zeros_like(p, dtype=torch.float32) for p in params]
+        g = _zero_grads(params)
         _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g[:24])
         g_dx = d_pts if d_dx is None else (d_pts + d_dx.float()).contiguous()
         grad_d = torch.empty_like(act_d)
