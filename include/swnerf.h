@@ -187,6 +187,12 @@ int swnerf_deform_backward_dx(const float* packed_bwd, const float* bits_d, cons
 int swnerf_query_points(const float* packed, const float* pts, int64_t M, const float* dirs, int64_t n_dirs,
                         int shared_dirs, int L_pos, int L_dir, float* out /*[M,4]*/, void* stream);
 
+/* Coarse sampling of render_rays on its own (nerf/run.py:355-385): z_vals [N,S] = near(1-t)+far*t with t = linspace(0,1,S)
+ * (or the lindisp form, :365), stratified jitter when t_rand [N,S] is given (:369-383: replaces torch.rand);
+ * pts [N,S,3] = rays_o + rays_d * z (:385) may be NULL.  ray_batch as for swnerf_render_pass (columns 0-7 are read). */
+int swnerf_sample_coarse(const float* ray_batch, int64_t n_rays, int cols, int n_samples, int lindisp,
+                         const float* t_rand, float* z_vals /*[N,S]*/, float* pts /*[N,S,3]*/, void* stream);
+
 /* ---- fused render pass (render_rays, nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480) -------
  * One wavefront owns one ray: sampling -> positional encoding -> MLP (MFMA, register
  * resident) -> alpha compositing -> optional hierarchical resampling, with no HBM traffic

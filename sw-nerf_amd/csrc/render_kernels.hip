@@ -365,6 +365,36 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     return sw_check(hipGetLastError(), "render_pass launch");
 }
 
+// Coarse sampling alone (nerf/run.py:355-385; API parity for the op-by-op path - the fused pass does this in
+// registers): z_vals [N,S] and, when asked, pts = o + d*z [N,S,3].  Same device functions as the fused pass.
+__global__ void __launch_bounds__(256) sample_coarse_kernel(swnerf_pass_args a, float* z_out, float* pts) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int S = a.n_samples;
+    if (idx >= a.n_rays * S) return;
+    const int64_t ray = idx / S;
+    const int s = (int)(idx - ray * S);
+    const float* rb = a.ray_batch + ray * a.cols;
+    const float z = z_sample(a, ray, rb[6], rb[7], s);
+    z_out[idx] = z;
+    if (pts) {
+        pts[idx * 3 + 0] = rb[0] + rb[3] * z;
+        pts[idx * 3 + 1] = rb[1] + rb[4] * z;
+        pts[idx * 3 + 2] = rb[2] + rb[5] * z;
+    }
+}
+
+extern "C" int swnerf_sample_coarse(const float* ray_batch, int64_t n_rays, int cols, int n_samples, int lindisp,
+                                    const float* t_rand, float* z_vals, float* pts, void* stream) {
+    if (n_rays == 0) return 0;                           // empty tensors have NULL data pointers
+    if (!ray_batch || !z_vals || n_rays < 0 || n_samples < 1 || cols < 8)
+        return sw_fail(SWNERF_E_ARG, "sample_coarse: NULL pointer, n_rays %lld, n_samples %d or cols %d < 8", (long long)n_rays, n_samples, cols);
+    swnerf_pass_args a = {};
+    a.ray_batch = ray_batch; a.n_rays = n_rays; a.cols = cols; a.n_samples = n_samples; a.lindisp = lindisp; a.t_rand = t_rand;
+    const int64_t total = n_rays * n_samples;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, z_vals, pts);
+    return sw_check(hipGetLastError(), "sample_coarse launch");
+}
+
 extern "C" int swnerf_query_points(const float* packed, const float* pts, int64_t M, const float* dirs, int64_t n_dirs,
                                    int shared_dirs, int L_pos, int L_dir, float* out, void* stream) {
     if (M == 0 && packed) return 0;

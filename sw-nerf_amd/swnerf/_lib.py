@@ -12,7 +12,7 @@ NET_CANON, NET_DNERF = 0, 1
 
 EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
-           "swnerf_sample_pdf", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
+           "swnerf_sample_pdf", "swnerf_sample_coarse", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
            "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
@@ -66,6 +66,7 @@ def lib():
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_sample_pdf.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_sample_coarse.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_embed.argtypes = [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_mlp_forward.argtypes = [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                      c_int, c_void_p, c_void_p, c_void_p]

@@ -194,19 +194,36 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     return ret
 
 
-def _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest):
-    """nerf/run.py:361-383 with torch ops (unfused path only)."""
-    t_vals = torch.linspace(0., 1., steps=N_samples, device=near.device)
+def sample_coarse(ray_batch, N_samples, lindisp=False, t_rand=None, want_pts=False):
+    """The coarse sampling of render_rays (nerf/run.py:355-385) as one HIP op: z_vals [N,S] (and pts [N,S,3])."""
+    rb = _lib.dev_f32(ray_batch, "ray_batch")
+    N, cols = rb.shape
+    z = torch.empty((N, int(N_samples)), dtype=torch.float32, device=rb.device)
+    pts = torch.empty((N, int(N_samples), 3), dtype=torch.float32, device=rb.device) if want_pts else None
+    tr = None if t_rand is None else _lib.dev_f32(t_rand, "t_rand", int(N_samples))
+    _lib.check(_lib.lib().swnerf_sample_coarse(_lib.ptr(rb), N, cols, int(N_samples), int(bool(lindisp)), _lib.ptr(tr),
+                                               _lib.ptr(z), _lib.ptr(pts), _lib.stream_of(rb)), "sample_coarse")
+    return (z, pts) if want_pts else z
+
+
+def _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest, ray_batch=None):
+    """nerf/run.py:361-383 (unfused path only): the HIP op when the ray batch is at hand, else torch ops."""
+    dev = near.device
+    t_rand = None
+    if perturb > 0.:
+        t_rand = torch.rand((N_rays, N_samples), device=dev)
+        if pytest:
+            np.random.seed(0)
+            t_rand = torch.Tensor(np.random.rand(N_rays, N_samples)).to(dev)
+    if ray_batch is not None and ray_batch.is_cuda:
+        return sample_coarse(ray_batch.detach(), N_samples, lindisp, t_rand)
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=dev)
     z_vals = near * (1. - t_vals) + far * t_vals if not lindisp else 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
     z_vals = z_vals.expand([N_rays, N_samples])
-    if perturb > 0.:
+    if t_rand is not None:
         mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
         upper = torch.cat([mids, z_vals[..., -1:]], -1)
         lower = torch.cat([z_vals[..., :1], mids], -1)
-        t_rand = torch.rand(z_vals.shape, device=near.device)
-        if pytest:
-            np.random.seed(0)
-            t_rand = torch.Tensor(np.random.rand(*list(z_vals.shape))).to(near.device)
         z_vals = lower + (upper - lower) * t_rand
     return z_vals
 
@@ -220,7 +237,7 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
     viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
     bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
     near, far = bounds[..., 0], bounds[..., 1]
-    z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest)
+    z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest, ray_batch)
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw = network_query_fn(pts, viewdirs, network_fn)
     rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)

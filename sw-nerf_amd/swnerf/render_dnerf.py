@@ -139,7 +139,7 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
     if fused_coarse is not None:
         z_vals, z_std = fused_coarse["z_fine"], fused_coarse["z_std"]
     elif z_vals is None:
-        z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest)
+        z_vals = _coarse_z(near, far, N_rays, N_samples, lindisp, perturb, pytest, ray_batch)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
         if N_importance > 0:
             if use_two_models_for_fine:

@@ -124,6 +124,24 @@ def test_get_rays_ndc_golden(sw, dev, golden):
     assert torch.equal(dr, dfull.reshape(-1, 3)[400 * 100 + 7:400 * 100 + 1007])
 
 
+def test_sample_coarse_golden(sw, dev, golden):
+    """a5 as its own op (nerf/run.py:355-385): z_vals and pts against the reference's values (G3): linear and lindisp
+    spacing, with and without the stratified jitter (injected t_rand); and == the torch-op form of the same lines."""
+    g, ref = cases.g3_inputs(), golden("g3_coarse")
+    rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.).to(dev)
+    for lindisp in (False, True):
+        for perturb in (0, 1):
+            tr = T(g["t_rand"]).to(dev) if perturb else None
+            z, pts = sw.render.sample_coarse(rb, 64, lindisp, tr, want_pts=True)
+            assert z.shape == (256, 64) and pts.shape == (256, 64, 3)
+            close(pts[:32], ref[f"pts_l{int(lindisp)}_p{perturb}"], atol=2e-6, what=f"pts lindisp={lindisp} perturb={perturb}")
+            zo = O.coarse_z(T(g["near"]), T(g["far"]), 64, lindisp, T(g["t_rand"]) if perturb else None)
+            close(z, zo, atol=1e-6, what="z_vals")
+    assert sw.render.sample_coarse(rb[:0], 64).shape == (0, 64)
+    z7 = sw.render.sample_coarse(rb[:5], 7)                  # odd sample count: the two-sided linspace formula
+    close(z7, O.coarse_z(T(g["near"][:5]), T(g["far"][:5]), 7), atol=0.0, what="S=7")
+
+
 @pytest.mark.parametrize("S", [64, 192])
 def test_raw2outputs_golden(sw, dev, golden, S):
     g, ref = cases.g5_inputs(S), golden(f"g5_raw2outputs_S{S}")
