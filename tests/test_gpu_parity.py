@@ -206,6 +206,31 @@ def test_sample_pdf_golden(sw, dev, golden):
     assert bool((zs[:, 1:] >= zs[:, :-1]).all())
 
 
+@pytest.mark.parametrize("N", [1, 100])
+@pytest.mark.parametrize("nb", [2, 51, 501])
+@pytest.mark.parametrize("ns", [1, 12, 120])
+def test_sample_pdf_size_sweep(sw, dev, N, nb, ns):
+    """The size grid of the reference's only unit test for this path (d_nerf/torchsearchsorted/test/test_searchsorted.py:9-44:
+    batches {1,100,..} x sorted lengths {1,50,500} x query counts {1,12,120}), applied to the op the search lives in:
+    well-conditioned weights (every bin carries mass), random u plus u that hit cdf values exactly (ties go right:
+    ray.py:136 `right=True`), against the oracle."""
+    rng = np.random.default_rng(1000 * N + 10 * nb + ns)
+    bins = np.sort(rng.uniform(2, 6, (N, nb)).astype(np.float32), -1)
+    w = rng.uniform(0.5, 1.5, (N, nb - 1)).astype(np.float32)
+    u = rng.uniform(0, 1, (N, ns)).astype(np.float32)
+    wn = w + np.float32(1e-5)
+    cdf = np.concatenate([np.zeros((N, 1), np.float32), np.cumsum(wn / wn.sum(-1, keepdims=True), -1, dtype=np.float32)], -1)
+    if ns > 1:
+        u[:, 0] = cdf[:, min(1, nb - 1)]                       # exact ties with an interior / the last cdf value
+        u[:, -1] = 0.0
+    ref = O.sample_pdf(T(bins), T(w), ns, det=False, u=T(u))
+    got = sw.ray.sample_pdf(T(bins).to(dev), T(w).to(dev), ns, det=False, u=T(u).to(dev))
+    assert got.shape == (N, ns)
+    # a tie may resolve to either neighbouring bin when the two float32 cumsums differ in the last bit: both answers
+    # lie at the shared bin edge, so the samples still agree
+    close(got, ref, atol=5e-5, what=f"sample_pdf N={N} nb={nb} ns={ns}")
+
+
 # ---------------------------------------------------------------------------------- model.py
 def _load(sw, cls, sd_np, dev, **kw):
     m = cls(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True, **kw)
