@@ -35,6 +35,9 @@ def test_mfma_kernels_isa(asm):
     import isa_audit
     seen = {}
     for name, body in isa_audit.kernels(asm):
+        if "sample_coarse_kernel" in name:          # the one non-MFMA kernel of these translation units
+            assert "v_mfma" not in body and "scratch_" not in body
+            continue
         stats, bad = isa_audit.audit(body)
         assert not bad, f"{name}: {len(bad)} uses of in-flight asm-load registers, e.g. {bad[0]}"
         dma = len(re.findall(r"global_load_lds_dwordx4", body))
