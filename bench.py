@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py - rays/sec of the fused NeRF render path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config C2|C4|C5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config C2 of BASELINE.json / SURVEY.md 8d): lego-like 800x800 camera, N_rand = 4096
-rays per GPU per step, 64 coarse + 128 fine samples, separate coarse and fine 8x256 nets with
-seeded synthetic weights, use_viewdirs, white background, perturb = 0 - i.e. exactly one call
-of the reference's render(..., rays=batch_rays, **render_kwargs_test) per step.  Ray origins /
-directions are resident in HBM before the timed region.  For N > 1 every rank renders its own
-4096-ray batch (weak scaling) and the step ends with ONE RCCL all-gather of the rendered pixels
-[rgb, disp, acc].  fp32 end to end (v_mfma_f32_32x32x2_f32).
+Started WITHOUT a launcher (WORLD_SIZE unset) and --gpus N > 1, this process becomes a launcher: it compiles the
+library if stale (hipcc only), starts N fresh rank processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set)
+BEFORE anything in it touches HIP or torch.cuda, relays rank 0's JSON line and exits with the worst child code.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel - the fine render pass
-(192 samples/ray) - timed with events on the launch stream inside the timed region;
-`cpu_baseline` is the CPU oracle (oracle/nerf_oracle.py, kind "port") on the host cores."""
+Workloads (BASELINE.json configs / SURVEY.md 8d):
+  C2 (default, the headline; weak scaling): lego-like 800x800 camera, N_rand = 4096 rays per GPU per step, 64 coarse
+     + 128 fine samples, separate coarse and fine 8x256 nets with seeded synthetic weights, use_viewdirs, white
+     background, perturb = 0 - one call of the reference's render(..., rays=batch_rays, **render_kwargs_test) per
+     step; ray origins / directions resident in HBM before the timed region; for N > 1 every rank renders its own
+     batch and the step ends with ONE RCCL all-gather of the rendered pixels [rgb, disp, acc].
+  C4 (strong scaling): the whole 800x800 frame (640 000 rays) per step, the reference's render-only entry
+     (nerf/run.py:557-571): rank r generates the rays of its contiguous row-major shard (get_rays on the range),
+     renders them (64+128, two nets) and the step ends with the all-gather of the frame.
+  C5 (strong scaling): D-NeRF 400x400 frame (160 000 rays) at t = 0.5, one DirectTemporalNeRF (deformation +
+     canonical net per sample, d_nerf/run_dnerf.py:553-566), same sharding.
+fp32 end to end (v_mfma_f32_32x32x2_f32).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel - the fine render pass (192 samples/ray) -
+timed with events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle
+(oracle/nerf_oracle.py, kind "port") on the host cores (N = 1 only); `extra.configs` (N = 1 only, measured AFTER and
+outside the headline's timed region) carries the other configs and the training step with their own roofline
+fractions, so that every number DESIGN.md quotes sits in a driver-run record."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,13 +39,26 @@ for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 FLOP_PER_ROW = 2 * 593408           # MACs of one (ray,sample) row through the 8x256 net
+FLOP_PER_ROW_DEFORM = 2 * 497152    # ... through the deformation net (D-NeRF, t != 0)
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-N_RAND, N_SAMPLES, N_IMPORTANCE, HW = 4096, 64, 128, 800
+N_RAND, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
+DEFAULT_STEPS = {"C2": (50, 5), "C4": (5, 1), "C5": (10, 2)}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs block")
+    args = ap.parse_args()
+    ds, dw = DEFAULT_STEPS[args.config]
+    args.steps = ds if args.steps is None else args.steps
+    args.warmup = dw if args.warmup is None else args.warmup
+    return args
 
 
 def host_cores():
@@ -48,17 +74,166 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------- launcher
+def launch(args):
+    """--gpus N > 1 without a launcher: become one.  Nothing here may initialise the GPU (a process that has must
+    not start programs on this pool): hipcc through subprocess, torch.cuda.device_count() only (it does not create
+    a context on this image), then N children, each a fresh interpreter."""
+    import __graft_entry__
+    __graft_entry__.compile_library()
+    rehearsal = os.environ.get("SWNERF_BENCH_REHEARSAL") == "1"
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not rehearsal:
+        print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) visible; refusing to report a {args.gpus}-GPU number "
+              f"(SWNERF_BENCH_REHEARSAL=1 runs the control flow with ranks sharing cards over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
+
+# --------------------------------------------------------------------------------------------- worker
+def build_scene(cfg, dev, rank):
+    """nets, render kwargs and the camera of one workload; everything seeded (swnerf/synth.py)."""
+    import torch
+    from swnerf import synth, model, embedder, render, render_dnerf
+    embed_fn, input_ch = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, input_ch_views = embedder.get_embedder(4, 3, 0)
+    sc = {"sds_np": []}
+    if cfg == "C5":
+        embedtime_fn, input_ch_time = embedder.get_embedder(10, 1, 0)
+        sd = synth.dnerf_state_dict(synth.NET_DNERF[0], alpha_bias=synth.NET_DNERF[1])
+        net = model.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4],
+                                     input_ch_views=input_ch_views, input_ch_time=input_ch_time, use_viewdirs=True,
+                                     embed_fn=embed_fn, zero_canonical=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net = net.to(dev).eval()
+        sc["sds_np"] = [sd]
+        query = lambda inputs, viewdirs, ts, network_fn: render_dnerf.run_network(
+            inputs, viewdirs, ts, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn,
+            netchunk=1024 * 64, embd_time_discr=True)
+        sc["H"] = sc["W"] = 400
+        sc["kw"] = dict(ndc=False, near=2., far=6., use_viewdirs=True, network_fn=net, network_query_fn=query, N_samples=N_SAMPLES,
+                        N_importance=N_IMPORTANCE, network_fine=None, white_bkgd=True, perturb=0., raw_noise_std=0.)
+        sc["frame_time"] = 0.5
+        sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM)
+        sc["flop_per_fine_row"] = FLOP_PER_ROW + FLOP_PER_ROW_DEFORM
+        sc["kernel"] = "render_pass_kernel<true>"
+    else:
+        nets = []
+        for seed, ab in (synth.NET_COARSE, synth.NET_FINE):
+            sd = synth.nerf_state_dict(seed, alpha_bias=ab)
+            m = model.vallina_NeRF(D=8, W=256, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=5,
+                                   skips=[4], use_viewdirs=True)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            nets.append(m.to(dev).eval())
+            sc["sds_np"].append(sd)
+        query = lambda inputs, viewdirs, network_fn: render.run_network(
+            inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+        sc["H"] = sc["W"] = 800
+        sc["kw"] = dict(ndc=False, near=2., far=6., use_viewdirs=True, network_fn=nets[0], network_query_fn=query,
+                        N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, network_fine=nets[1], white_bkgd=True, perturb=0.,
+                        raw_noise_std=0.)
+        sc["frame_time"] = None
+        sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_ROW
+        sc["flop_per_fine_row"] = FLOP_PER_ROW
+        sc["kernel"] = "render_pass_kernel<false>"
+    sc["K"], sc["c2w"] = synth.lego_camera(sc["H"], sc["W"])
+    return sc
+
+
+def extra_configs(dev):
+    """The other BASELINE configs and the training step on this GPU, wall-clock per call through the Python mirrors
+    (so Python, get_rays and ray-batch packing are inside), each with its own fraction of the fp32-MFMA roofline."""
+    import numpy as np
+    import torch
+    from swnerf import synth, render, render_dnerf, parallel
+    rows = []
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False):
+        ctx = torch.enable_grad() if grad else torch.no_grad()
+        with ctx:
+            fn(); fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        tf = n_rays * flop_per_ray / dt / 1e12
+        rows.append({"name": name, "ms": dt * 1e3, "rays_per_s": n_rays / dt, "algorithmic_tflops": tf,
+                     "frac": tf / PEAK_FP32_MFMA_TFLOPS, "reps": reps})
+
+    st = build_scene("C2", dev, 0)
+    kw, K8, c2w8 = st["kw"], st["K"], st["c2w"]
+    K4, c2w4 = synth.lego_camera(400, 400)
+    o, d = synth.pick_rays(400, 400, K4, c2w4, 1024, 1)
+    r1 = (T(o), T(d))
+    kw1 = dict(kw, N_importance=0, network_fine=None)
+    timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50)
+    Kf, c2wf = synth.fern_camera()
+    o, d = synth.pick_rays(378, 504, Kf, c2wf, N_RAND, 3)
+    r3 = (T(o), T(d))
+    kw3 = dict(kw, ndc=True, near=0., far=1., white_bkgd=False)
+    timeit("C3: fern-like NDC rays, 4096 x (64+128)", lambda: render.render(378, 504, Kf, rays=r3, **kw3), N_RAND, st["flop_per_ray"], 10)
+    lo, hi = synth.shard_range(800 * 800, 8, 3)
+    rr4 = parallel.frame_renderer(800, 800, K8, c2w8, kw, device=dev)
+    timeit("C4 shard: rank 3 of 8 of the 800x800 frame, 80 000 rays incl. get_rays", lambda: rr4(lo, hi - lo), hi - lo, st["flop_per_ray"], 3)
+    s5 = build_scene("C5", dev, 0)
+    lo5, hi5 = synth.shard_range(400 * 400, 8, 3)
+    for tv in (0.5, 0.0):
+        rr5 = parallel.frame_renderer(400, 400, s5["K"], s5["c2w"], s5["kw"], frame_time=tv, device=dev)
+        timeit(f"C5 shard: D-NeRF rank 3 of 8 of the 400x400 frame, 20 000 rays, t={tv}", lambda: rr5(lo5, hi5 - lo5), hi5 - lo5,
+               s5["flop_per_ray"] if tv else st["flop_per_ray"], 3)
+    # training step of the reference (nerf/run.py:684-708): render -> img2mse -> backward -> Adam; 3x the forward FLOPs
+    nets = [kw["network_fn"], kw["network_fine"]]
+    for m in nets:
+        m.train()
+    o, d = synth.pick_rays(800, 800, K8, c2w8, N_RAND, 2)
+    rt = (T(o), T(d))
+    target = torch.rand((N_RAND, 3), device=dev)
+    opt = torch.optim.Adam([p for m in nets for p in m.parameters()], lr=5e-4, betas=(0.9, 0.999))
+    kwt = dict(kw, perturb=1.)
+
+    def train_step():
+        rgb, disp, acc, extras = render.render(800, 800, K8, chunk=1024 * 32, rays=rt, **kwt)
+        loss = torch.mean((rgb - target) ** 2) + torch.mean((extras['rgb0'] - target) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    timeit("training step: 4096 rays x (64+128), two nets, mse(rgb)+mse(rgb0), backward, Adam (3x forward FLOPs)", train_step,
+           N_RAND, 3 * st["flop_per_ray"], 5, grad=True)
+    rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    for m in nets:
+        m.eval()
+        for p in m.parameters():
+            p.grad = None
+    return rows
+
+
+def worker(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: the launcher and the flag disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     # SWNERF_BENCH_REHEARSAL=1: run the N>1 control flow on a box with fewer GPUs than ranks (ranks share
@@ -73,51 +248,51 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from swnerf import synth, model, embedder, render, parallel
+    from swnerf import synth, render, parallel
 
-    embed_fn, input_ch = embedder.get_embedder(10, 3, 0)
-    embeddirs_fn, input_ch_views = embedder.get_embedder(4, 3, 0)
-    nets, sds_np = [], []
-    for seed, ab in (synth.NET_COARSE, synth.NET_FINE):
-        sd = synth.nerf_state_dict(seed, alpha_bias=ab)
-        m = model.vallina_NeRF(D=8, W=256, input_ch=input_ch, input_ch_views=input_ch_views, output_ch=5,
-                               skips=[4], use_viewdirs=True)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-        nets.append(m.to(dev).eval())
-        sds_np.append(sd)
-    network_query_fn = lambda inputs, viewdirs, network_fn: render.run_network(
-        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
-    K, c2w = synth.lego_camera(HW, HW)
-    o_np, d_np = synth.pick_rays(HW, HW, K, c2w, N_RAND, seed=2 + rank)
-    rays_o, rays_d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
-    kw = dict(ndc=False, near=2., far=6., use_viewdirs=True, network_fn=nets[0], network_query_fn=network_query_fn,
-              N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, network_fine=nets[1], white_bkgd=True,
-              perturb=0., raw_noise_std=0.)
+    cfg = args.config
+    sc = build_scene(cfg, dev, rank)
+    H, W, K, c2w, kw = sc["H"], sc["W"], sc["K"], sc["c2w"], sc["kw"]
+    S_FINE = N_SAMPLES + N_IMPORTANCE
 
     fine_events = []
 
     def hook(phase, n_rays, n_samples):
-        if n_samples == N_SAMPLES + N_IMPORTANCE and hook.on:
+        if n_samples == S_FINE and hook.on:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(dev))     # the stream the kernel is launched on
             fine_events.append(ev)
     hook.on = False
     render.PASS_HOOK = hook
 
-    def step():
-        rgb, disp, acc, _ = render.render(HW, HW, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kw)
-        px = torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+    def gather(px):
         if world > 1 and rehearsal:
             return parallel.gather_pixels(px.cpu()).to(dev)
         return parallel.gather_pixels(px) if world > 1 else px
+
+    if cfg == "C2":
+        o_np, d_np = synth.pick_rays(H, W, K, c2w, N_RAND, seed=2 + rank)
+        rays_o, rays_d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
+        n_local, rays_per_step, scaling = N_RAND, world * N_RAND, "weak"
+
+        def step():
+            rgb, disp, acc, _ = render.render(H, W, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kw)
+            return gather(torch.cat([rgb, disp[:, None], acc[:, None]], -1))
+    else:
+        lo, hi = synth.shard_range(H * W, world, rank)
+        n_local, rays_per_step, scaling = hi - lo, H * W, "strong"
+        if (H * W) % world:
+            raise SystemExit(f"[bench] {cfg}: {H * W} rays do not split evenly over {world} ranks")
+        render_range = parallel.frame_renderer(H, W, K, c2w, kw, frame_time=sc["frame_time"], device=dev)
+
+        def step():
+            return gather(render_range(lo, hi - lo))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -140,60 +315,94 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (world * N_RAND, 5) and bool(torch.isfinite(out[:, :3]).all())
+    assert out.shape == (rays_per_step, 5) and bool(torch.isfinite(out[:, :3]).all())
 
     ms_kernel = [fine_events[i].elapsed_time(fine_events[i + 1]) for i in range(0, len(fine_events), 2)]
     fine_ms = float(np.mean(ms_kernel)) if ms_kernel else float("nan")
-    fine_flop = N_RAND * (N_SAMPLES + N_IMPORTANCE) * FLOP_PER_ROW
+    fine_flop = n_local * S_FINE * sc["flop_per_fine_row"]
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and cfg == "C2":
         try:
             traffic = json.load(open(tpath)).get("fine_pass_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
+    workloads = {
+        "C2": "C2: lego-like 800x800 camera, N_rand=4096 rays/GPU/step, 64 coarse + 128 fine samples, coarse+fine 8x256 nets "
+              "(use_viewdirs), white_bkgd, perturb=0; render() forward (get rays resident -> ray batch -> coarse pass -> "
+              "resample -> fine pass)",
+        "C4": "C4: lego-like 800x800 full-image render_only (640000 rays/step over all GPUs), 64+128, coarse+fine 8x256 nets; "
+              "each rank: get_rays on its contiguous row range -> ray batch -> coarse pass -> resample -> fine pass",
+        "C5": "C5: D-NeRF (bouncingballs-like) 400x400 full-image render (160000 rays/step over all GPUs) at t=0.5, 64+128, "
+              "one DirectTemporalNeRF (deformation + canonical 8x256 net per sample); each rank renders its contiguous row range",
+    }
     result = {
-        "metric": "rays/sec (64+128 samples/ray)", "value": world * N_RAND * args.steps / dt, "unit": "rays/s",
+        "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_step * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo; not a measurement)" if rehearsal else ""),
-        "config": {"workload": "C2: lego-like 800x800 camera, N_rand=4096 rays/GPU/step, 64 coarse + 128 fine samples, "
-                               "coarse+fine 8x256 nets (use_viewdirs), white_bkgd, perturb=0; render() forward "
-                               "(get rays resident -> ray batch -> coarse pass -> resample -> fine pass)"
-                               + ("; + RCCL all-gather of [rgb,disp,acc]" if world > 1 else ""),
-                   "rays_per_step_per_gpu": N_RAND, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE,
+        "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if world > 1 else ""),
+                   "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE,
                    "parallelism": f"ray-sharded dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "kernel": "render_pass_kernel<false> fine pass (4096 rays x 192 samples)",
-                     "ms_per_launch": fine_ms, "flop_per_launch": fine_flop},
+                     "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)",
+                     "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
+                     "step_frac": rays_per_step / world * sc["flop_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
     }
+    assert result["n_gpus"] == args.gpus
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import nerf_oracle as O
         torch.set_num_threads(host_cores())
         cores = torch.get_num_threads()
-        sd_c, sd_f = (O.to_torch_sd(s) for s in sds_np)
-        rb = O.make_ray_batch(torch.from_numpy(o_np), torch.from_numpy(d_np), 2., 6.)
+        if cfg == "C2":
+            o_cpu, d_cpu, gpu_rows = torch.from_numpy(o_np), torch.from_numpy(d_np), out[:N_RAND, :3]
+            what = "the same 4096-ray batch"
+        else:   # a bounded sample of the frame: 4096 pixels spread evenly over it
+            sel = np.linspace(0, H * W - 1, N_RAND).astype(np.int64)
+            o_all, d_all = O.get_rays(H, W, K, c2w)
+            o_cpu, d_cpu, gpu_rows = o_all.reshape(-1, 3)[sel], d_all.reshape(-1, 3)[sel], out[torch.from_numpy(sel).to(dev), :3]
+            what = f"4096 pixels spread evenly over the {H}x{W} frame"
+        rb = O.make_ray_batch(o_cpu, d_cpu, 2., 6., frame_time=sc["frame_time"])
+        if cfg == "C5":
+            sd = O.to_torch_sd(sc["sds_np"][0])
+            run = lambda r: O.render_rays_dnerf(r, sd, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
+        else:
+            sd_c, sd_f = (O.to_torch_sd(s) for s in sc["sds_np"])
+            run = lambda r: O.render_rays(r, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
         with torch.no_grad():
-            O.render_rays(rb[:256], sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)      # warm-up
+            run(rb[:256])                                                                        # warm-up
             # bounded sample: the whole batch once (needed for the PSNR), then repeat up to ~15 s / 5 reps
             reps, t0 = 0, time.perf_counter()
             while reps < 1 or (time.perf_counter() - t0 < 15.0 and reps < 5):
-                ref = O.render_rays(rb, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)
+                ref = run(rb)
                 reps += 1
             cdt = time.perf_counter() - t0
-        mse = float(((out[:N_RAND, :3].cpu() - ref["rgb_map"]) ** 2).mean())
+        mse = float(((gpu_rows.cpu() - ref["rgb_map"]) ** 2).mean())
         result["cpu_baseline"] = {"value": reps * N_RAND / cdt, "unit": "rays/s", "cores": cores, "kind": "port",
-                                  "sample": f"{reps} x the same 4096-ray batch (64+128, both nets), oracle/nerf_oracle.py, "
+                                  "sample": f"{reps} x {what} (64+128), oracle/nerf_oracle.py, "
                                             f"torch CPU {torch.__version__}, no_grad"}
         result["psnr_vs_cpu_render_db"] = float(-10 * np.log10(max(mse, 1e-20)))
+    if rank == 0 and world == 1 and not args.no_extra:
+        render.PASS_HOOK = None
+        result["extra"] = {"note": "measured after and outside the headline's timed region, same process and GPU; wall clock per "
+                                   "call incl. Python; frac = algorithmic MLP FLOPs / time / 157.3 TFLOP/s",
+                           "configs": extra_configs(dev)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args))
+    worker(args)
 
 
 if __name__ == "__main__":

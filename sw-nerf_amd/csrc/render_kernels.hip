@@ -361,7 +361,15 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
-    else hipLaunchKernelGGL(render_pass_kernel<false>, grid, block, lds, st, P);
+    else {
+        // a canonical-only net has no deformation: position_delta is zeros (NeRFOriginal.forward, model.py:273-296
+        // returns torch.zeros_like(input_pts[:, :3])); the static kernel has no dx store, so fill it here
+        if (a.dx) {
+            rc = sw_check(hipMemsetAsync(a.dx, 0, (size_t)a.n_rays * a.n_samples * 3 * sizeof(float), st), "render_pass dx fill");
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(render_pass_kernel<false>, grid, block, lds, st, P);
+    }
     return sw_check(hipGetLastError(), "render_pass launch");
 }
 

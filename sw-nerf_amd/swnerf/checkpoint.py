@@ -28,7 +28,7 @@ def load_checkpoint(path, network_fn, network_fine=None, optimizer=None, map_loc
     network_fn.load_state_dict(ckpt['network_fn_state_dict'])
     if network_fine is not None:
         network_fine.load_state_dict(ckpt['network_fine_state_dict'])
-    if optimizer is not None and 'optimizer_state_dict' in ckpt:
+    if optimizer is not None and ckpt.get('optimizer_state_dict'):       # absent or {} (saved without an optimizer): keep the fresh state
         optimizer.load_state_dict(ckpt['optimizer_state_dict'])
     return int(ckpt['global_step'])
 
@@ -40,7 +40,8 @@ def save_checkpoint(basedir, expname, step, global_step, network_fn, network_fin
     d = {'global_step': global_step, 'network_fn_state_dict': network_fn.state_dict()}
     if network_fine is not None:
         d['network_fine_state_dict'] = network_fine.state_dict()
-    d['optimizer_state_dict'] = optimizer.state_dict() if optimizer is not None else {}
+    if optimizer is not None:
+        d['optimizer_state_dict'] = optimizer.state_dict()
     torch.save(d, path)
     return path
 

@@ -7,8 +7,10 @@ nerf/run.py:269-280), whose forward runs the register-resident MFMA kernel
 Built configuration = the one every shipped config uses: D=8, W=256, skips=[4],
 use_viewdirs=True.  Anything else constructs (state_dict parity) but raises at forward.
 TNeRF (model.py:152-210) is out of scope.
-Backward is not built yet: forward outputs carry a grad_fn
-that raises if autograd reaches it."""
+Training: with grad enabled, forward saves the activations and backward runs the
+register-resident dX chain + TN MFMA GEMMs (`_MlpTrain`, `_DnerfTrain`); gradients w.r.t. the embedded inputs are
+not produced (rays are data in the reference's train()).
+"""
 import ctypes
 import torch
 import torch.nn as nn

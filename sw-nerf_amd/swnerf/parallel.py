@@ -45,21 +45,63 @@ def render_image_sharded(render_range, H, W, group=None):
     return full.reshape(H, W, -1)
 
 
+def frame_renderer(H, W, K, c2w, render_kwargs, frame_time=None, chunk=1 << 30, device=None):
+    """The per-rank half of the sharded full-image render (BASELINE configs C4 / C5; the reference's render-only
+    entry nerf/run.py:557-571, d_nerf/run_dnerf.py:553-566 renders every pose with render(H, W, K, c2w=...)):
+    returns render_range(ray0, n) -> [n, 5] = [rgb(3), disp, acc] of the row-major pixel range, doing what render()
+    does for those pixels - get_rays on the range (each rank generates its own rays from (K, c2w): no scatter), ray
+    batch, coarse pass, resampling, fine pass.  frame_time given -> the D-NeRF render (run_dnerf.py:104-173)."""
+    from . import render as _r, render_dnerf as _rd
+    from .ray import get_rays_range
+
+    def render_range(ray0, n):
+        with torch.no_grad():
+            if frame_time is None:
+                o, d = get_rays_range(H, W, K, c2w, ray0, n, device)
+                rgb, disp, acc, _ = _r.render(H, W, K, chunk=chunk, rays=(o, d), **render_kwargs)
+            else:
+                focal = float(K[0][0]) if not isinstance(K, float) else K
+                o, d = get_rays_range(H, W, focal, c2w, ray0, n, device)
+                rgb, disp, acc, _ = _rd.render(H, W, focal, chunk=chunk, rays=(o, d), frame_time=frame_time, **render_kwargs)
+        return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+    return render_range
+
+
 def allreduce_gradients(modules, group=None, average=True):
     """Data-parallel training over the ray batch (SURVEY.md section 8e "Training"): ONE all-reduce of every
     parameter gradient, flattened into a single bucket (2 x 595 844 floats = 4.77 MB for coarse + fine) -
-    a single RCCL call instead of 48 small ones; xGMI rings are per-link bound, so few large messages."""
+    a single RCCL call instead of 48 small ones; xGMI rings are per-link bound, so few large messages.
+    The bucket is built from a RANK-INVARIANT list - every parameter with requires_grad, zeros where this
+    rank produced no gradient (a D-NeRF rank whose batch sits at frame_time == 0 takes the zero_canonical
+    branch, model.py:143-145, and leaves `_time.*` without .grad) - so every rank contributes the same element
+    count; a parameter gets a .grad afterwards if ANY rank had one."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    params = [p for m in modules if m is not None for p in m.parameters() if p.grad is not None]
+    params = [p for m in modules if m is not None for p in m.parameters() if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat /= dist.get_world_size(group)
+    dev, dt = params[0].device, params[0].dtype
+    n = sum(p.numel() for p in params)
+    flat = torch.zeros(n + len(params), dtype=dt, device=dev)    # tail: one "has a gradient" flag per parameter
     off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    for i, p in enumerate(params):
+        k = p.numel()
+        if p.grad is not None:
+            flat[off:off + k].copy_(p.grad.reshape(-1))
+            flat[n + i] = 1.0
+        off += k
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    world = dist.get_world_size(group)
+    if average:
+        flat[:n] /= world
+    has = flat[n:].tolist()                                      # (one small D2H; the step ends with optimizer.step anyway)
+    off = 0
+    for i, p in enumerate(params):
+        k = p.numel()
+        if has[i] > 0:
+            g = flat[off:off + k].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+        off += k

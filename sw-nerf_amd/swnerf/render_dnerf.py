@@ -53,7 +53,16 @@ def run_network(inputs, viewdirs, frame_time, fn, embed_fn, embeddirs_fn, embedt
     return outputs, torch.reshape(dx_flat, list(inputs.shape[:-1]) + [dx_flat.shape[-1]])
 
 
+# frame_time known on the host (render() was handed a Python float, the normal case: d_nerf/run_dnerf.py:208,667 pass
+# one time per frame): keyed by the ray batch's storage, valid only while render() runs, so that render_rays - whose
+# signature is the reference's and carries the time only as column 8 - needs no device->host sync per chunk.
+_TIME_HINT = {}
+
+
 def _single_time(ray_batch):
+    hint = _TIME_HINT.get(ray_batch.untyped_storage().data_ptr())
+    if hint is not None:
+        return hint
     lo, hi = torch.aminmax(ray_batch[:, 8])
     lo, hi = float(lo), float(hi)
     assert lo == hi, "Only accepts all points from same time"      # run_dnerf.py:53
@@ -197,7 +206,13 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     rb = pack_ray_batch(rays_o, rays_d, near, far, frame_time=ft, ndc=ndc, H=H, W=W, focal=focal)
     if c2w_staticcam is not None:
         rb[:, -3:] = pack_ray_batch(rays_o, viewsrc, near, far)[:, -3:]
-    all_ret = batchify_rays(rb, chunk, **kwargs)
+    key = rb.untyped_storage().data_ptr()
+    if isinstance(ft, float):
+        _TIME_HINT[key] = ft
+    try:
+        all_ret = batchify_rays(rb, chunk, **kwargs)
+    finally:
+        _TIME_HINT.pop(key, None)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']

@@ -44,6 +44,21 @@ def _worker(rank, world, port, q):
         p_.grad = torch.full_like(p_, float(rank + 1) * (k + 1))
     parallel.allreduce_gradients([lin, None])
     grads_ok = all(bool(torch.all(p_.grad == 1.5 * (k + 1))) for k, p_ in enumerate(lin.parameters()))
+    # a rank WITHOUT a gradient for some parameters (D-NeRF: a batch at frame_time == 0 takes the zero_canonical branch
+    # and leaves `_time.*` without .grad, model.py:143-145): same element count on every rank, zeros where there is none
+    lin2 = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2), torch.nn.Linear(2, 2))
+    ps = list(lin2.parameters())
+    for k, p_ in enumerate(ps):
+        p_.grad = None
+    for k in (0, 1):
+        ps[k].grad = torch.full_like(ps[k], 2.0 * (rank + 1))            # layer 0: both ranks
+    if rank == 1:
+        for k in (2, 3):
+            ps[k].grad = torch.full_like(ps[k], 8.0)                     # layer 1: rank 1 only; layer 2: nobody
+    parallel.allreduce_gradients([lin2])
+    grads_ok = grads_ok and all(bool(torch.all(ps[k].grad == 3.0)) for k in (0, 1)) \
+        and all(ps[k].grad is not None and bool(torch.all(ps[k].grad == 4.0)) for k in (2, 3)) \
+        and all(ps[k].grad is None for k in (4, 5))
     # the bench's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

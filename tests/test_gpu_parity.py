@@ -173,14 +173,24 @@ def test_raw2outputs_ragged(sw, dev):
         sw.ray.raw2outputs(torch.zeros((2, 1, 4), device=dev), torch.zeros((2, 1), device=dev), torch.ones((2, 3), device=dev))
 
 
+MAX_FLIPS_G6 = {"det": 64, "rnd": 64}       # of 16 384 samples each; tightened to the measured counts below
+
+
 def test_sample_pdf_golden(sw, dev, golden):
     g, ref = cases.g6_inputs(), golden("g6_sample_pdf")
     bins, w = T(g["bins"]).to(dev), T(g["weights"]).to(dev)
     s_det = sw.ray.sample_pdf(bins, w, 128, det=True)
     s_rnd = sw.ray.sample_pdf(bins, w, 128, det=False, pytest=True)
-    # hard bound = one bin width: a sample whose bin flips across the denom threshold stays in its bin
-    close_mostly(s_det, ref["det"], atol=2e-5, frac=0.99, hard=0.2, what="sample_pdf det")
-    close_mostly(s_rnd, ref["rnd"], atol=2e-5, frac=0.99, hard=0.2, what="sample_pdf rnd")
+    # hard bound = the width of the bin each reference sample was drawn in: a sample whose bin flips across the denom
+    # threshold stays in its bin; and the NUMBER of such samples is bounded (measured on MI355X: see the print)
+    for name, got_s in (("det", s_det), ("rnd", s_rnd)):
+        bound = bin_width_bound(got_s.cpu().numpy(), ref[name], g["bins"])
+        dlt = np.abs(got_s.cpu().numpy().astype(np.float64) - ref[name])
+        assert np.all(dlt <= bound * 1.0001 + 1e-6), f"sample_pdf {name}: a sample left the bin it was drawn in"
+        nfl = flips(got_s, ref[name])
+        print(f"\n[parity] sample_pdf {name}: {nfl} of {dlt.size} samples differ by > 2e-5; max {dlt.max():.3e} (bin widths {bound.min():.3f}..{bound.max():.3f})")
+        assert nfl <= MAX_FLIPS_G6[name], f"sample_pdf {name}: {nfl} flipped samples"
+        close_mostly(got_s, ref[name], atol=2e-5, frac=0.995, hard=float(bound.max()) + 1e-6, what=f"sample_pdf {name}")
     # the well-conditioned statement of the same thing: cdf(sample) == u.  Evaluate the reference
     # piecewise-linear cdf (float64) at our samples and compare with the u that produced them.
     wn = g["weights"].astype(np.float64) + 1e-5
@@ -200,7 +210,8 @@ def test_sample_pdf_golden(sw, dev, golden):
     sd = torch.empty((128,), device=dev)
     _lib.check(_lib.lib().swnerf_sample_pdf(_lib.ptr(bins), _lib.ptr(w), 128, 63, 128, None, _lib.ptr(smp), _lib.ptr(z), 64,
                                             _lib.ptr(zs), _lib.ptr(sd), _lib.stream_of(z)), "sample_pdf")
-    close_mostly(zs, ref["z_det"], atol=2e-5, frac=0.99, hard=0.2, what="sorted union")
+    zb = float(np.diff(g["bins"], axis=-1).max())
+    close_mostly(zs, ref["z_det"], atol=2e-5, frac=0.995, hard=zb + 1e-6, what="sorted union")
     close(sd, ref["std_det"], atol=2e-3, what="z_std")
     assert torch.equal(torch.sort(torch.cat([z, smp], -1), -1)[0], zs)      # the merge itself is exact
     assert bool((zs[:, 1:] >= zs[:, :-1]).all())
@@ -311,11 +322,32 @@ def _rb(g, dev, t=None):
 RGB_TOL = dict(atol=2e-5, rtol=0)          # outputs NOT downstream of resampling (measured ~1e-6 on MI355X)
 
 
-def _cmp(ret, ref, keys, what, nraw=32, resampled=True, scale=1.0, psnr_min=65.0):
+def bin_width_bound(got, ref, edges):
+    """Per-element bound for samples drawn by sample_pdf: a sample whose bin flips across the reference's own
+    `denom < 1e-5 -> 1` threshold (ray.py:148-149) stays inside the bin it was drawn in, so |got - ref| <= the
+    width of THAT bin (edges [N, nb], sorted; bin of the reference sample), not a global constant."""
+    e = np.asarray(edges, np.float64)
+    r = np.asarray(ref, np.float64)
+    idx = np.stack([np.clip(np.searchsorted(e[i], r[i], side="right") - 1, 0, e.shape[1] - 2) for i in range(e.shape[0])])
+    lo = np.take_along_axis(e, idx, 1)
+    hi = np.take_along_axis(e, idx + 1, 1)
+    return hi - lo
+
+
+def flips(got, ref, atol=2e-5):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    return int((np.abs(got.astype(np.float64) - ref) > atol).sum())
+
+
+# Measured on MI355X (round 2, profiles/r02/parity_measured.md): per case the fraction of resampled pixels within
+# 2e-4 of the reference render and the PSNR against it.  The floors below sit 3 dB under the measured PSNR and a few
+# points under the measured fraction; the conditioning argument is in close_mostly's docstring and DESIGN.md 6.
+def _cmp(ret, ref, keys, what, nraw=32, resampled=True, scale=1.0, psnr_min=65.0, frac_min=0.95, hard=5e-2):
     """Compare a render_rays dict with the golden one.  rgb0/disp0/acc0 (and everything when
     N_importance == 0) are held to 2e-5 abs.  Outputs downstream of the hierarchical resampling
-    (see close_mostly) are held to: median within 2e-5, >= 75 % within 2e-4 (the SURVEY.md 8d
-    figure), all within 5e-2, and - for the colours - PSNR >= 65 dB against the reference render
+    (see close_mostly) are held to: >= 75 % within 2e-5, >= frac_min within 2e-4 (the SURVEY.md 8d
+    figure), all within `hard`, and - for the colours - PSNR >= psnr_min dB against the reference render
     (8-bit quantisation noise sits at 58.9 dB).  `scale` widens the two atol bands for D-NeRF with
     t != 0, where gamma(x + dx) multiplies the 2e-7 rounding of dx by 2^9 before the canonical net
     (measured: the ORACLE moves by the same 2e-4 in raw under a +-2e-7 shift of x+dx)."""
@@ -333,15 +365,30 @@ def _cmp(ret, ref, keys, what, nraw=32, resampled=True, scale=1.0, psnr_min=65.0
             else:
                 close(v, ref[k], what=w, **RGB_TOL)
         elif k == "z_vals":
-            close_mostly(v, ref[k], atol=2e-5, frac=0.97, hard=0.2, what=w)
+            # sorted union of 64 coarse depths (exact) and 128 drawn samples: an element moves by at most the widest
+            # coarse interval of its row when a sample flips (per-row bound from the reference's own z)
+            rz = np.asarray(ref[k], np.float64)
+            gz = v.detach().cpu().numpy().astype(np.float64)
+            # (linear coarse spacing: the union runs from near to far, so one coarse interval = (last - first) / 63)
+            row_bound = (rz[:, -1:] - rz[:, :1]) / 63.0 * 1.0001 + 1e-6
+            assert np.all(np.abs(gz - rz) <= row_bound), f"{w}: an element moved by more than one coarse interval"
+            nfl = flips(gz, rz)
+            print(f"\n[parity] {w}: {nfl} of {gz.size} depths differ by > 2e-5 ({100 * nfl / gz.size:.3f} %)")
+            close_mostly(v, ref[k], atol=2e-5, frac=0.99, hard=float(row_bound.max()), what=w)
         elif k == "z_std":
             close(v, ref[k], atol=2e-3, what=w)
         elif k in ("raw", "position_delta"):
             close_mostly(v, ref[k], atol=5e-3, frac=0.9, hard=60.0, what=w)    # a moved sample is a different point
         else:
             rel = k == "disp_map"
-            close_mostly(v, ref[k], atol=2e-5 * scale, frac=0.5, hard=5e-2, what=w, rel=rel)
-            close_mostly(v, ref[k], atol=2e-4 * scale, frac=0.75, hard=5e-2, what=w, rel=rel)
+            a_ = v.detach().cpu().numpy()
+            d_ = np.abs(np.nan_to_num(a_) - np.nan_to_num(np.asarray(ref[k])))
+            if rel:
+                d_ = d_ / np.maximum(1.0, np.abs(np.nan_to_num(np.asarray(ref[k]))))
+            print(f"\n[parity] {w}: within 2e-5 {float((d_ <= 2e-5 * scale).mean()):.4f}, within 2e-4 {float((d_ <= 2e-4 * scale).mean()):.4f}, "
+                  f"max {float(d_.max()):.2e}")
+            close_mostly(v, ref[k], atol=2e-5 * scale, frac=0.75, hard=hard, what=w, rel=rel)
+            close_mostly(v, ref[k], atol=2e-4 * scale, frac=frac_min, hard=hard, what=w, rel=rel)
             if k == "rgb_map" and v.shape[0] >= 128:
                 db = psnr(v, ref[k])
                 print(f"\n[parity] {w}: PSNR vs reference render {db:.1f} dB, max|d| {maxdiff(v, ref[k]):.2e}")
@@ -489,7 +536,8 @@ def test_render_rays_dnerf_golden(sw, dev, golden, nets):
         self_db = psnr(pert["rgb_map"], ref["rgb_map"][:256])
         ours_db = psnr(r["rgb_map"][:256], ref["rgb_map"][:256])
         print(f"\n[parity] dnerf t={tv}: PSNR ours vs reference {ours_db:.1f} dB; reference vs itself under a 2e-7 shift of dx {self_db:.1f} dB")
-        assert ours_db >= min(65.0, self_db - 6.0)
+        # absolute floor (measured 55.3 dB, round 1 and 2) AND the self-calibration (within 3 dB of what a 2e-7 shift does to the reference)
+        assert ours_db >= 52.0 and ours_db >= min(65.0, self_db - 3.0)
         close_mostly(r["rgb_map"], ref["rgb_map"], atol=2e-3, frac=0.75, hard=0.2, what="dnerf t=0.5 rgb")
         close_mostly(r["z_vals"], ref["z_vals"], atol=2e-5, frac=0.9, hard=0.2, what="dnerf t=0.5 z_vals")
         # the same pass with NO resampling in between is tight
@@ -549,6 +597,110 @@ def test_mesh_grid_query_golden(sw, dev, golden, nets):
     assert mesh.query_points(nets["fine"], pts[:0], dirs, shared_dirs=True).shape == (0, 4)
     with pytest.raises(RuntimeError, match="one per point"):
         mesh.query_points(nets["fine"], pts[:10], dirs, shared_dirs=False)
+
+
+# ----------------------------------------------------------------- a4: the ray-batch pack, on its own
+def test_pack_ray_batch_direct(sw, dev):
+    """swnerf_pack_ray_batch (nerf/run.py:137-158, d_nerf/run_dnerf.py:137-160) against the oracle's restatement of the
+    same lines, column by column: 11 and 12 columns, ndc on/off (view directions are normalised BEFORE the NDC warp),
+    scalar and per-ray near/far, a stride-0 rays_o (what get_rays returns)."""
+    Kf, c2wf = cases.synth.fern_camera()
+    o, d = cases.synth.pick_rays(378, 504, Kf, c2wf, 777, seed=41)          # N not a multiple of the block size
+    rng = np.random.default_rng(42)
+    near_a = rng.uniform(0.5, 2.0, (777,)).astype(np.float32)
+    far_a = (near_a + rng.uniform(1.0, 4.0, (777,))).astype(np.float32)
+    for ndc in (False, True):
+        for ft in (None, 0.0, 0.625):
+            ref = O.make_ray_batch(T(o), T(d), 2., 6., frame_time=ft, ndc=ndc, H=378, W=504, focal=float(Kf[0][0]))
+            got = sw.render.pack_ray_batch(T(o).to(dev), T(d).to(dev), 2., 6., frame_time=ft, ndc=ndc, H=378, W=504, focal=float(Kf[0][0]))
+            assert got.shape == ref.shape == (777, 11 if ft is None else 12)
+            cols = got.shape[1]
+            close(got[:, 6:cols - 3], ref[:, 6:cols - 3], atol=0, what="near/far/(t) columns")
+            close(got[:, -3:], ref[:, -3:], atol=1.2e-7, what="viewdirs")                    # d/|d|: 1 ulp of the rsqrt/div chain
+            close(got[:, :6], ref[:, :6], atol=2e-7 if ndc else 0, rtol=2e-6 if ndc else 0, what=f"o,d ndc={ndc}")
+    # per-ray near/far arrays (render()'s docstring allows them), 2-D [H,W,3] inputs, stride-0 origin
+    ref = O.make_ray_batch(T(o), T(d), T(near_a)[:, None], T(far_a)[:, None])
+    got = sw.render.pack_ray_batch(T(o).to(dev), T(d).to(dev), T(near_a).to(dev), T(far_a).to(dev))
+    close(got[:, 6], ref[:, 6], atol=0, what="near array")
+    close(got[:, 7], ref[:, 7], atol=0, what="far array")
+    centre = T(o[:1]).to(dev).expand(21, 37, 3)
+    got = sw.render.pack_ray_batch(centre, T(d[:777].reshape(21, 37, 3)).to(dev), 2., 6.)
+    close(got[:, :3], np.broadcast_to(o[:1], (777, 3)), atol=0, what="stride-0 rays_o")
+    assert sw.render.pack_ray_batch(T(o[:0]).to(dev), T(d[:0]).to(dev), 2., 6.).shape == (0, 11)
+
+
+def test_render_rays_dnerf_with_original_net(sw, dev, nets):
+    """run_dnerf.py with nerf_type='original' (model.py:214-225, 227-296): the canonical net alone behind the D-NeRF
+    render_rays; position_delta is ZEROS (NeRFOriginal.forward returns torch.zeros_like(input_pts[:, :3])), the
+    colours equal the static render of the same weights."""
+    qd = _query_d(sw)
+    g = cases.g8_inputs()
+    rb = _rb(g, dev, 0.5)[:200]
+    assert sw.render.fused_plan(qd, [nets["orig"], None], need_time=True) == (10, 4, 10)
+    for Ni in (0, 128):
+        r = sw.render_dnerf.render_rays(rb, nets["orig"], qd, 64, retraw=True, N_importance=Ni, white_bkgd=True,
+                                        use_two_models_for_fine=False)
+        S = 64 + Ni
+        assert r["position_delta"].shape == (200, S, 3) and float(r["position_delta"].abs().max()) == 0.0
+        ref = O.render_rays(_rb(g, "cpu")[:200], O.to_torch_sd(cases.weights_static()[1]), None, 64, Ni, white_bkgd=True)
+        if Ni == 0:
+            close(r["rgb_map"], ref["rgb_map"], what="original-in-dnerf rgb", **RGB_TOL)
+        else:
+            close_mostly(r["rgb_map"], ref["rgb_map"], atol=2e-4, frac=0.9, hard=5e-2, what="original-in-dnerf rgb (resampled)")
+    r2 = sw.render_dnerf.render_rays(rb, nets["orig"], qd, 64, N_importance=128, white_bkgd=True, use_two_models_for_fine=True,
+                                     network_fine=nets["orig"])
+    assert float(r2["position_delta_0"].abs().max()) == 0.0 and r2["position_delta_0"].shape == (200, 64, 3)
+
+
+def test_rng_paths_statistics(sw, dev, nets):
+    """perturb=1 / raw_noise_std>0 WITHOUT injected randoms (torch's generator; the reference draws torch.rand /
+    torch.randn at the same three places: nerf/run.py:375-377, ray.py:117-121, :176-178).  Not bit-comparable, so:
+    moments + a Kolmogorov-Smirnov distance of the stratified jitter and of the inverse-CDF samples, and the
+    Monte-Carlo mean of the render against the deterministic one."""
+    torch.manual_seed(1234)
+    g = cases.g7_inputs(n=512, seed=77)
+    rb = _rb(g, dev)
+    q = _query(sw)
+    # (1) stratified jitter (nerf/run.py:369-383): z = lower + (upper-lower) * U[0,1) per (ray, sample)
+    t_rand, u, noise = sw.render._rng_inputs(512, 64, 128, 1., 1., False, dev)
+    z = sw.render.sample_coarse(rb, 64, False, t_rand)
+    z0 = sw.render.sample_coarse(rb, 64, False, None)
+    mids = .5 * (z0[:, 1:] + z0[:, :-1])
+    upper, lower = torch.cat([mids, z0[:, -1:]], -1), torch.cat([z0[:, :1], mids], -1)
+    assert bool((z >= lower - 1e-6).all()) and bool((z <= upper + 1e-6).all())
+    frac = ((z - lower) / (upper - lower))[:, 1:-1].reshape(-1).double().cpu().numpy()       # should be U[0,1)
+    n = frac.size
+    ks = float(np.abs(np.sort(frac) - (np.arange(n) + 0.5) / n).max())
+    assert ks < 1.63 / np.sqrt(n) * 1.5, f"stratified jitter: KS distance {ks:.4f} (n={n})"   # 1 % critical value x 1.5
+    assert abs(frac.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n) and abs(frac.var() - 1 / 12) < 0.002
+    nz = noise(64).double().cpu().numpy().reshape(-1)
+    assert abs(nz.mean()) < 4 / np.sqrt(nz.size) and abs(nz.std() - 1.0) < 0.02               # randn * raw_noise_std
+    # (2) inverse-CDF samples with random u: cdf(sample) must be U[0,1) again (probability integral transform)
+    p0 = sw.render.render_pass(rb, nets["coarse"], 64, white_bkgd=True, want=["weights", "z_out"])
+    w, zc = p0["weights"], p0["z_out"]
+    bins = .5 * (zc[:, 1:] + zc[:, :-1])
+    smp = sw.ray.sample_pdf(bins, w[:, 1:-1], 128, det=False)
+    wn = w[:, 1:-1].double().cpu().numpy() + 1e-5
+    cdf = np.concatenate([np.zeros((512, 1)), np.cumsum(wn / wn.sum(-1, keepdims=True), -1)], -1)
+    back = np.stack([np.interp(smp[r].double().cpu().numpy(), bins[r].double().cpu().numpy(), cdf[r]) for r in range(512)])
+    # rows whose mass sits in bins of < 1e-5 snap to bin edges (ray.py:148-149) - the transform is only uniform where
+    # the pdf is positive, so test rows that spread their mass
+    spread = (wn / wn.sum(-1, keepdims=True)).max(-1) < 0.5
+    b = np.sort(back[spread].reshape(-1))
+    ks2 = float(np.abs(b - (np.arange(b.size) + 0.5) / b.size).max())
+    assert spread.sum() >= 32 and ks2 < 0.02, f"sample_pdf random u: KS distance {ks2:.4f} over {spread.sum()} rows"
+    # (3) end to end: the mean of 16 perturbed renders approaches the deterministic render (the estimator is
+    # consistent; a stuck or mis-scaled generator shows up as a bias)
+    kw = dict(N_importance=128, network_fine=nets["fine"], white_bkgd=True)
+    det = sw.render.render_rays(rb, nets["coarse"], q, 64, perturb=0., **kw)["rgb_map"]
+    runs = torch.stack([sw.render.render_rays(rb, nets["coarse"], q, 64, perturb=1., **kw)["rgb_map"] for _ in range(16)], 0)
+    assert float((runs[0] - runs[1]).abs().max()) > 1e-4                                       # the draws differ
+    spread_px = runs.std(0).mean()
+    bias = (runs.mean(0) - det).abs().mean()
+    print(f"\n[parity] rng: KS jitter {ks:.4f}, KS inverse-cdf {ks2:.4f}, per-pixel std {float(spread_px):.4f}, |mean - det| {float(bias):.4f}")
+    assert float(bias) < 0.5 * float(spread_px) + 2e-3
+    noisy = sw.render.render_rays(rb, nets["coarse"], q, 64, perturb=0., raw_noise_std=1.0, **kw)["rgb_map"]
+    assert float((noisy - det).abs().max()) > 1e-5 and bool(torch.isfinite(noisy).all())
 
 
 # ------------------------------------------------------------------ full-size properties + report
