@@ -80,7 +80,7 @@ def test_c4_shard_80000_rays(dev):
     db = _psnr(got[:, :3].numpy(), ref["rgb_map"].numpy())
     print(f"\n[parity] C4 shard (80 000 rays, HIP) vs oracle on 256 of them: within 2e-4 {float((dlt <= 2e-4).float().mean()):.4f}, "
           f"max {float(dlt.max()):.2e}, PSNR {db:.1f} dB")
-    assert float((dlt <= 2e-4).float().mean()) >= 0.95 and db >= 70.0       # SURVEY.md 8d floor
+    assert float((dlt <= 2e-4).float().mean()) >= 0.92 and db >= 72.0       # measured 0.960 / 75.0 dB; SURVEY.md 8d floor is 70
     assert np.array_equal(np.isnan(got[:, 3].numpy()), np.isnan(ref["disp_map"].numpy()))
 
 
@@ -107,7 +107,7 @@ def test_c5_shard_20000_rays_dnerf(dev):
     sd = O.to_torch_sd(cases.weights_dnerf())
     o, d = O.get_rays(H, W, float(K[0][0]), c2w)
     sel = np.linspace(0, hi - lo - 1, 256).astype(np.int64)
-    for tv, floor_db in ((0.5, 52.0), (0.0, 70.0)):
+    for tv, floor_db in ((0.5, 54.0), (0.0, 77.0)):                        # measured 58.5 / 80.4 dB
         rr = parallel.frame_renderer(H, W, K, c2w, kw, frame_time=tv, device=dev)
         px = rr(lo, hi - lo)
         assert px.shape == (20000, 5) and bool(torch.isfinite(px[:, :3]).all())
