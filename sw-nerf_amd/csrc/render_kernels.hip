@@ -3,7 +3,7 @@
 // For each 32-sample tile of its ray the wave computes depths -> points -> positional
 // encoding (VALU) -> [deformation MLP ->] canonical MLP (MFMA, registers: mlp_core.h) ->
 // alpha compositing (wave scan), and after the last tile optionally the hierarchical
-// resampling (inverse-CDF + bitonic merge in the wave's LDS slice).  Nothing per-sample
+// resampling (inverse-CDF + rank merge in the wave's LDS slice).  Nothing per-sample
 // touches HBM unless the caller asks for it (raw / weights / dx / z_out).
 //
 // Reference: render_rays nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480; raw2outputs
@@ -25,12 +25,34 @@ struct PassDev {
     const float* b0;        // its bias stream
     int nbias;              // floats in the bias stream (multiple of 32)
     int two_pass;           // 1: deformation net then canonical net
-    int sort_n;             // power of two >= S + n_importance
+    int sort_n, sort_s;     // powers of two >= n_importance / >= n_samples (fallback sort of an unsorted list)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// Ascending in-place sort of buf[0..n) by one wave, ONLY if it is not already sorted (wave-uniform test); n_pow2 =
+// power of two >= n, buf has room for n_pow2 floats (the pad is filled with +inf).  Bitonic network.
+__device__ __forceinline__ void wave_sort_if_unsorted(float* buf, int n, int n_pow2, int lane) {
+    bool sorted = true;
+    for (int m = lane; m + 1 < n; m += 64) sorted = sorted && (buf[m] <= buf[m + 1]);
+    if (__all(sorted)) return;
+    for (int i = n + lane; i < n_pow2; i += 64) buf[i] = __builtin_inff();
+    wave_lds_sync();
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int idx = lane; idx < (n_pow2 >> 1); idx += 64) {
+                const int i = 2 * idx - (idx & (jj - 1));
+                const int l = i + jj;
+                const float x = buf[i], y = buf[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { buf[i] = y; buf[l] = x; }
+            }
+            wave_lds_sync();
+        }
+    }
 }
 
 __device__ __forceinline__ float wave32_sum(float v) {   // sum over the 32 lanes of each half
@@ -243,35 +265,51 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         float den = ca - cb;
         if (den < 1e-5f) den = 1.f;
         const float smp = bb + (u - cb) / den * (ba - bb);
-        srt[S + m] = smp;
+        srt[m] = smp;
         sm += (double)smp;
     }
-    for (int i = lane; i < S; i += 64) srt[i] = zc[i];
-    for (int i = S + Ni + lane; i < P.sort_n; i += 64) srt[i] = __builtin_inff();
     wave_lds_sync();
     if (a.z_std) {                                   // torch.std(z_samples, unbiased=False), nerf/run.py:416
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
         const double mean = sm / Ni;
         double var = 0.0;
-        for (int m = lane; m < Ni; m += 64) { const double d = (double)srt[S + m] - mean; var += d * d; }
+        for (int m = lane; m < Ni; m += 64) { const double d = (double)srt[m] - mean; var += d * d; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
         if (lane == 0) a.z_std[ray] = (float)sqrt(var / Ni);
     }
-    for (int k = 2; k <= P.sort_n; k <<= 1) {        // bitonic sort of the wave's slice
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int idx = lane; idx < (P.sort_n >> 1); idx += 64) {
-                const int i = 2 * idx - (idx & (jj - 1));
-                const int l = i + jj;
-                const float x = srt[i], y = srt[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) { srt[i] = y; srt[l] = x; }
-            }
-            wave_lds_sync();
+    // ---- z_vals = sort(cat[z_vals, z_samples]) (nerf/run.py:400) as a MERGE of two sorted lists.
+    // The coarse depths are sorted by construction (linspace, or jitter inside disjoint strata).  The samples are
+    // sorted when u is (det: linspace; the inverse cdf is monotone) - up to a last-bit inversion where one bin ends
+    // and the next begins, and not at all for random u - so that is CHECKED, and only an unsorted list is sorted
+    // first (bitonic, on the Ni samples alone).  Then each element's slot = its own index + the number of elements
+    // of the other list in front of it (ties: coarse depths first), found by binary search in the wave's LDS
+    // slice: 13 dependent LDS reads per lane instead of the 36 barrier-separated stages of a 256-element bitonic
+    // sort.  Any correct sort yields the same values as torch.sort.
+    // (The coarse list is checked too: it arrives sorted except, in principle, for a last-bit inversion between two
+    // jittered strata, or when a caller hands unsorted z_vals to a resampling pass.)
+    wave_sort_if_unsorted(srt, Ni, P.sort_n, lane);
+    wave_sort_if_unsorted(zc, S, P.sort_s, lane);
+    float* zf = a.z_fine + ray * (S + Ni);
+    for (int i = lane; i < S; i += 64) {             // coarse depth i goes behind the samples strictly below it
+        const float v = zc[i];
+        int lo = 0, hi = Ni;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (srt[mid] < v) lo = mid + 1; else hi = mid;
         }
+        zf[i + lo] = v;
     }
-    for (int i = lane; i < S + Ni; i += 64) a.z_fine[ray * (S + Ni) + i] = srt[i];
+    for (int m = lane; m < Ni; m += 64) {            // sample m goes behind the coarse depths <= it
+        const float v = srt[m];
+        int lo = 0, hi = S;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (zc[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        zf[m + lo] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -346,15 +384,18 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     P.a = a;
     int rc = stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
-    P.sort_n = 0;
+    P.sort_n = 0; P.sort_s = 0;
     size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine && a.n_rays != 0) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
         if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
             return sw_fail(SWNERF_E_UNSUPP, "render_pass: resampling supports 3<=N_samples<=%d and N_samples+N_importance<=%d", SW_LDS_SC, SW_LDS_SORT);
-        int p2 = 2;
-        while (p2 < a.n_samples + a.n_importance) p2 <<= 1;
+        int p2 = 2;                              // fallback sort of an unsorted sample list: power of two >= n_importance
+        while (p2 < a.n_importance) p2 <<= 1;
         P.sort_n = p2;
+        p2 = 2;
+        while (p2 < a.n_samples) p2 <<= 1;
+        P.sort_s = p2;
         lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
     }
     if (a.n_rays == 0) return 0;

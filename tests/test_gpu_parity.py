@@ -725,6 +725,21 @@ def test_c2_full_size_properties(sw, dev, nets):
     merged = torch.sort(torch.cat([zf, p0["z_out"]], -1), -1)[0]
     assert int((merged[:, 1:] == merged[:, :-1]).sum(-1).min()) >= 64
     close(p0["weights"].sum(-1), p0["acc_map"], atol=2e-6, what="sum(weights) == acc")
+    # the merge behind the resampling (render_kernels.hip): random u (unsorted samples) and UNSORTED depths handed in
+    # both take the sort-first branch; the result is still the sorted union containing every input depth
+    g_ = torch.Generator(device="cpu").manual_seed(5)
+    u_r = torch.rand((512, 128), generator=g_).to(dev)
+    z_sh = p0["z_out"][:512][:, torch.randperm(64, generator=g_).to(dev)].contiguous()
+    for zin, uin in ((None, u_r), (z_sh, None), (z_sh, u_r)):
+        pm = sw.render.render_pass(rb[:512], nets["coarse"], 64, z_vals=zin, white_bkgd=True, want=["z_out"], n_importance=128, u=uin)
+        zm = pm["z_fine"]
+        assert bool((zm[:, 1:] >= zm[:, :-1]).all())
+        both = torch.sort(torch.cat([zm, pm["z_out"]], -1), -1)[0]
+        assert int((both[:, 1:] == both[:, :-1]).sum(-1).min()) >= 64
+    pm0 = sw.render.render_pass(rb[:512], nets["coarse"], 64, white_bkgd=True, want=["weights", "z_out"], n_importance=128, u=u_r)
+    bins_ = .5 * (pm0["z_out"][:, 1:] + pm0["z_out"][:, :-1])
+    smp_ = sw.ray.sample_pdf(bins_, pm0["weights"][:, 1:-1], 128, u=u_r)
+    assert torch.equal(pm0["z_fine"], torch.sort(torch.cat([pm0["z_out"], smp_], -1), -1)[0])     # == torch.sort of the op path
     assert bool((p0["weights"] >= 0).all()) and float(p0["acc_map"].max()) <= 1.0 + 1e-5
     p1 = sw.render.render_pass(rb, nets["fine"], 192, z_vals=zf, white_bkgd=True, want=["rgb_map", "acc_map", "weights"])
     close(p1["weights"].sum(-1), p1["acc_map"], atol=2e-6, what="sum(weights) == acc (fine)")
