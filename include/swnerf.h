@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 101
+#define SWNERF_VERSION 102
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -231,6 +231,38 @@ typedef struct swnerf_pass_args {
 } swnerf_pass_args;
 
 int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);
+
+/* ---- the fused pass under autograd: loss.backward() of the reference's training step --------------------------
+ * (nerf/run.py:684-708: render -> img2mse(rgb) + img2mse(rgb0) -> backward -> optimizer.step)
+ * Static net (SWNERF_NET_CANON, 11-column ray batch), 2 <= n_samples <= 256.
+ *
+ * render_pass_train: exactly swnerf_render_pass (same sampling / encoding / MLP / compositing / resampling
+ * arithmetic, same outputs) and additionally saves what the backward needs.  Rows of the saved buffers are the
+ * (ray, sample) rows PADDED to whole 32-sample tiles per ray: rows = swnerf_train_rows(N, S) = N * ceil(S/32) * 32,
+ * row = (ray * ceil(S/32) + s/32) * 32 + s%32.
+ *   act  [rows, swnerf_act_floats_per_row()]   post-ReLU activations (as swnerf_mlp_forward_train)
+ *   bits [swnerf_mask_floats(rows)]            ReLU bit masks
+ *   xs   [rows, swnerf_xs_floats_per_row()]    gamma(x) (64 slots) and gamma(d) (32 slots) in the kernel's operand
+ *                                              slot order; swnerf_unslot_grad maps slot columns back
+ * args->raw and the depths (args->z_vals given, or args->z_out) are required: the backward recomputes the
+ * compositing from them.
+ *
+ * render_pass_backward: gradients of (rgb_map, disp_map, acc_map) -> d raw [rows,4] (padded rows; zeros past S) and
+ * the gradient of every layer's pre-activation grad [rows, act floats] (as swnerf_mlp_backward_dx), one wavefront
+ * per ray: compositing backward in the wave's LDS slice, then the dX chain tile by tile.  packed_bwd:
+ * swnerf_pack_net_bwd_kind(SWNERF_BWD_CANON).  g_* may each be NULL.  z_vals [N,S]: the depths the forward used. */
+int64_t swnerf_train_rows(int64_t n_rays, int n_samples);
+int swnerf_xs_floats_per_row(void);
+int swnerf_render_pass_train(const swnerf_pass_args* args /*HOST*/, float* act, float* bits, float* xs, void* stream);
+int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, const float* raw /*[N,S,4]*/,
+                                const float* z_vals /*[N,S]*/, const float* ray_batch, int cols, const float* noise,
+                                int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb /*[N,3]*/,
+                                const float* g_disp /*[N]*/, const float* g_acc /*[N]*/, float* grad, float* d_raw,
+                                void* stream);
+/* Cs [rows_w, nslots] holds weight-gradient columns in slot order (a TN GEMM against xs[:, slot0 : slot0+nslots]):
+ * W[o][col0 + column(slot0 + f)] = Cs[o][f] for every real slot f; pad slots are dropped. */
+int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nslots, int L_pos, int L_dir,
+                       float* W, int ldw, int col0, void* stream);
 
 #ifdef __cplusplus
 }

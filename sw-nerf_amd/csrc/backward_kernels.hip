@@ -527,3 +527,28 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
     else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, block, 0, st, P);
     return sw_check(hipGetLastError(), "gemm_tn launch");
 }
+
+// ---------------------------------------------------------------------------------------------
+// The fused training pass keeps gamma(x) / gamma(d) in B-operand slot order (swnerf_common.h sw_xs_col), so the
+// weight-gradient GEMMs against them come out with slot-ordered columns: Cs[rows, nslots].  This moves every real
+// slot to its reference column: W[o][col0 + sw_xs_col(slot0 + f)] = Cs[o][f]  (each column has exactly one slot;
+// pad slots are dropped).
+__global__ void __launch_bounds__(256) unslot_kernel(const float* Cs, int ld_s, int rows, int slot0, int nslots, int Lp, int Ld,
+                                                     float* W, int ldw, int col0) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nslots) return;
+    const int o = idx / nslots, f = idx - o * nslots;
+    const int col = sw_xs_col(slot0 + f, Lp, Ld);
+    if (col >= 0) W[(size_t)o * ldw + col0 + col] = Cs[(size_t)o * ld_s + f];
+}
+
+extern "C" int swnerf_unslot_grad(const float* Cs, int ld_s, int rows, int slot0, int nslots, int L_pos, int L_dir,
+                                  float* W, int ldw, int col0, void* stream) {
+    if (!Cs || !W || rows < 1 || nslots < 1 || slot0 < 0 || slot0 + nslots > SW_XS_LD || ld_s < nslots)
+        return sw_fail(SWNERF_E_ARG, "unslot_grad: bad arguments (rows=%d slot0=%d nslots=%d ld_s=%d)", rows, slot0, nslots, ld_s);
+    if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "unslot_grad: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
+    const int total = rows * nslots;
+    hipLaunchKernelGGL(unslot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Cs, ld_s, rows, slot0,
+                       nslots, L_pos, L_dir, W, ldw, col0);
+    return sw_check(hipGetLastError(), "unslot_grad launch");
+}

@@ -347,11 +347,13 @@ __device__ __forceinline__ void tile_fetch(const float* lds_tile, int lane, f32x
 // [M, SW_ACT_LD] buffer, + 4h) and its ReLU bit mask to mask_tile[256*l] (this lane's 16 bytes of the tile's
 // SW_MASK_TILE_FLOATS), both as side stores of the NEXT segment, whose B operand h_l is.  h_7 has no next
 // segment here: store_last writes it on the spot, otherwise the caller side-stores it (in `in`, mask in *mb).
-template <bool DNERF, bool TRAIN = false>
+// XS (fused training pass): the two position-encoding k-tiles go to xs_row (+ 4h; slot order, sw_xs_col) as side
+// stores of layer 0, whose B operand they are.
+template <bool DNERF, bool TRAIN = false, bool XS = false>
 __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_emb, float t, bool deform_pass, int h,
                                            f32x16 (&in)[8], f32x16 (&out)[8], float (&head)[3], WStream& ws,
                                            float* act_row = nullptr, float* mask_tile = nullptr, bool store_last = false,
-                                           f32x4* mb = nullptr) {
+                                           f32x4* mb = nullptr, float* xs_row = nullptr) {
     const int lane_ = threadIdx.x & 63;
     emb_park(lds_emb, lane_, emb);
     f32x4 mbits = {0.f, 0.f, 0.f, 0.f};
@@ -363,6 +365,8 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
                 k3[0] = emb[0]; k3[1] = emb[1];
                 pe_time(t, h, k3[2]);
                 seg_mfma<8, 3, SEG_BIAS>(out, k3, ws);
+            } else if (XS) {
+                seg_mfma<8, 2, SEG_BIAS, 2>(out, emb, ws, 1.f, SideStore{xs_row, nullptr, mbits});
             } else {
                 seg_mfma<8, 2, SEG_BIAS>(out, emb, ws);
             }
@@ -423,6 +427,29 @@ __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
+    head_valu<3, 4>(hv, ws, rgb);
+    rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
+}
+
+// The same tail in the training passes: h7 (`in`, ReLU mask `mb`) is side-stored by feature_linear's segment, the
+// feature by the view layer's; the view hidden layer and its mask are stored on the spot (act_row / mask_tile:
+// trunk_pass).
+__device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], f32x16 (&out)[8], const f32x16& demb,
+                                                 float (&rgb)[3], const float* hb_rgb, WStream& ws,
+                                                 float* act_row, float* mask_tile, const f32x4& mb) {
+    seg_mfma<8, 8, SEG_BIAS, 8>(out, in, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
+    f32x16 k9[9];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) k9[n] = out[n];
+    k9[8] = demb;
+    f32x16 hv[4];
+    seg_mfma<4, 9, SEG_BIAS, 8>(hv, k9, ws, 1.f, SideStore{act_row + SW_ACT_FEAT, nullptr, mb});
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
+    tiles_store<4>(act_row + SW_ACT_HV, hv);
+    *reinterpret_cast<f32x4*>(mask_tile + 256 * 8) = relu_bits<4>(hv);
     head_valu<3, 4>(hv, ws, rgb);
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
 }

@@ -100,6 +100,15 @@ SW_HD int sw_time_col(int a /*0..15*/, int h, int L) {
     return -1;
 }
 
+// fused training pass: the encodings as the kernel holds them, [rows, SW_XS_LD] in B-operand SLOT order -
+// k-tile kt (0,1: gamma(x); 2: gamma(d)), register r = 4g+e of lane half h sits at float 32*kt + 8g + 4h + e
+// (the same map as the activation tiles above).  sw_xs_col gives the reference column of a slot (-1: zero pad).
+#define SW_XS_LD 96
+SW_HD int sw_xs_col(int f /*0..95*/, int Lp, int Ld) {
+    const int kt = f >> 5, g = (f >> 3) & 3, h = (f >> 2) & 1, e = f & 3, r = 4 * g + e;
+    return kt < 2 ? sw_pos_col(16 * kt + r, h, Lp) : sw_dir_col(r, h, Ld);
+}
+
 // ---- sin / cos -------------------------------------------------------------------------
 // sin(y) for want_cos==0, cos(y) for want_cos==1, |y| up to ~1e5 (the top positional band is
 // 512*x).  Three-term Cody-Waite reduction by pi/2 with FMAs, then the Cephes float minimax

@@ -6,6 +6,7 @@
 // resampling scratch, and depth made no difference there.
 #define SW_RING 16
 #include "mlp_kernels.h"
+#include "render_pass.h"
 
 // ------------------------------------------------------------------------------------------
 // Backward of the MLP w.r.t. its activations (the "dX chain"), one wave per 32 rows, mirroring the
@@ -208,6 +209,158 @@ __global__ void __launch_bounds__(256, 1) deform_backward_dx_kernel(DeformBwdDev
     tiles_store<8>(grad_row, in);
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward of the fused render pass (static net): ONE wavefront owns ONE ray, like the forward.
+//   1. compositing backward (autograd of ray.py:155-198) from d rgb_map / d disp_map / d acc_map: forward recompute of
+//      T and w from the saved raw and depths, suffix sums of G.w in double, d raw of every sample -> the wave's LDS
+//      slice (and, padded to whole tiles, to HBM: the rgb_linear / alpha_linear weight-gradient GEMMs read it);
+//   2. per 32-sample tile the dX chain of mlp_backward_dx_kernel, seeded from LDS: d(pre-activation) of every layer
+//      -> grad[rows, SW_ACT_LD] as side stores.
+// Rows are the forward's padded rows: (ray * ntiles + tile) * 32 + j; samples past S get zero gradients.
+#define PB_SMAX 256
+#define PB_WAVE_FLOATS (6 * PB_SMAX)                 // T[S], w[S], d_raw[S][4]
+struct PassBwdDev {
+    const float* w0; const float* b0;                // backward stream (SWNERF_BWD_CANON); its 8 "bias" tiles = alpha_linear.weight
+    const float* bits;                               // [n_rays * ntiles, SW_MASK_TILE_FLOATS]
+    const float* raw; const float* z; const float* ray_batch; int cols; const float* noise;
+    int64_t n_rays; int S; int white;
+    const float* g_rgb; const float* g_disp; const float* g_acc;
+    float* grad; float* d_raw;                       // [rows, SW_ACT_LD], [rows, 4]
+};
+
+__global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev P) {
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    constexpr int BIASF = SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_all, P.b0, BIASF);
+    if (ray >= P.n_rays) return;
+    float* lds_ring = lds_all + BIASF + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
+    float* T_ = lds_all + BIASF + 4 * SW_LDS_RING_FLOATS + wv * PB_WAVE_FLOATS;
+    float* W_ = T_ + PB_SMAX;
+    float* dR = W_ + PB_SMAX;
+    const int S = P.S;
+    const int ntiles = (S + 31) >> 5;
+    const float* rb = P.ray_batch + ray * P.cols;
+    const float ddx = rb[3], ddy = rb[4], ddz = rb[5];
+    const float dnorm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+    const float* zv = P.z + ray * S;
+    const float* raw = P.raw + ray * S * 4;
+    WStream ws;
+    ws_start(ws, P.w0, lds_all, lds_ring, lane);      // the weight ring fills while the compositing backward runs
+
+    // ---- 1. compositing backward (the arithmetic of raw2outputs_bwd_kernel, backward_kernels.hip)
+    const float gr = P.g_rgb ? P.g_rgb[ray * 3] : 0.f, gg = P.g_rgb ? P.g_rgb[ray * 3 + 1] : 0.f, gb = P.g_rgb ? P.g_rgb[ray * 3 + 2] : 0.f;
+    double Tc = 1.0;
+    float pa = 0.f, pd = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        const float z = zv[sc];
+        float dist = (s + 1 < S) ? (zv[s + 1] - z) : 1e10f;
+        dist *= dnorm;
+        float sg = raw[sc * 4 + 3];
+        if (P.noise) sg += P.noise[ray * S + sc];
+        float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
+        if (!live) alpha = 0.f;
+        double ps = (double)(1.f - alpha + 1e-10f);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(ps, o, 64); if (lane >= o) ps *= up; }
+        double ex = __shfl_up(ps, 1, 64);
+        if (lane == 0) ex = 1.0;
+        const float T = (float)(Tc * ex);
+        Tc *= __shfl(ps, 63, 64);
+        const float w = alpha * T;
+        if (live) { T_[s] = T; W_[s] = w; }
+        pa += w; pd += w * z;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o, 64); pd += __shfl_xor(pd, o, 64); }
+    float gA = P.g_acc ? P.g_acc[ray] : 0.f, gD = 0.f;
+    if (P.white) gA -= (gr + gg + gb);
+    if (P.g_disp) {
+        const float q = pd / pa;                       // disp = 1/max(1e-10, q); no gradient on the clamped / NaN branch
+        if (q > 1e-10f) { const float gq = -P.g_disp[ray] / (q * q); gD += gq / pa; gA -= gq * pd / (pa * pa); }
+    }
+    wave_lds_sync();
+    double carry = 0.0;
+    const int nch = (S + 63) / 64;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int s = ch * 64 + lane;
+        const bool live = s < S;
+        const int sc = live ? s : S - 1;
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + sc * 4);
+        const float z = zv[sc];
+        const float c0 = 1.f / (1.f + expf(-r4[0])), c1 = 1.f / (1.f + expf(-r4[1])), c2 = 1.f / (1.f + expf(-r4[2]));
+        const float w = live ? W_[sc] : 0.f, T = live ? T_[sc] : 0.f;
+        const float G = gr * c0 + gg * c1 + gb * c2 + gA + gD * z;
+        double v = live ? (double)G * (double)w : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double dn = __shfl_down(v, o, 64); if (lane + o < 64) v += dn; }
+        double after = __shfl_down(v, 1, 64);
+        if (lane == 63) after = 0.0;
+        const double R = carry + after;
+        carry += __shfl(v, 0, 64);
+        float dist = (s + 1 < S) ? (zv[s + 1] - z) : 1e10f;
+        dist *= dnorm;
+        float sg = r4[3];
+        if (P.noise) sg += P.noise[ray * S + sc];
+        const float e = expf(-fmaxf(sg, 0.f) * dist);
+        const float p = 1.f - (1.f - e) + 1e-10f;
+        const float dLda = G * T - (float)(R / (double)p);
+        const float dsig = (sg > 0.f) ? dLda * dist * e : 0.f;
+        if (live) {
+            f32x4 o4 = {w * gr * c0 * (1.f - c0), w * gg * c1 * (1.f - c1), w * gb * c2 * (1.f - c2), dsig};
+            *reinterpret_cast<f32x4*>(dR + 4 * s) = o4;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- 2. the dX chain, tile by tile (mlp_backward_dx_kernel<false>)
+    const f32x4 nomask = {0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int s = tile * 32 + j;
+        const bool live = s < S;
+        const int64_t tix = ray * ntiles + tile;
+        const int64_t prow = tix * 32 + j;
+        f32x4 dr = *reinterpret_cast<const f32x4*>(dR + 4 * (live ? s : S - 1));
+        if (!live) dr = nomask;
+        if (h == 0) *reinterpret_cast<f32x4*>(P.d_raw + prow * 4) = dr;
+        float* grad_row = P.grad + prow * SW_ACT_LD + 4 * h;
+        MaskRing mr;
+        mask_start(mr, P.bits, tix, lds_emb + 2 * 16 * 64, lane);
+        mask_fetch(mr, 8);
+        f32x16 k1[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k1[0][r] = 0.f;
+        k1[0][0] = h ? 0.f : dr[0]; k1[0][1] = h ? 0.f : dr[1]; k1[0][2] = h ? 0.f : dr[2];
+        f32x16 dhv[4];
+        seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
+        mask_apply<4>(mask_take(mr), dhv);
+        mask_fetch(mr, 7);
+        f32x16 in[8], out[8];
+        seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
+        seg_mfma<8, 8, SEG_BIAS_SCALED, 8>(out, in, ws, dr[3], SideStore{grad_row + SW_ACT_FEAT, nullptr, nomask});
+#pragma nounroll
+        for (int l = 7; l >= 1; --l) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) in[n] = out[n];
+            mask_apply<8>(mask_take(mr), in);
+            mask_fetch(mr, l - 1);
+            seg_mfma<8, 8, SEG_ZERO, 8>(out, in, ws, 1.f, SideStore{grad_row + 256 * l, nullptr, nomask});
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) in[n] = out[n];
+        mask_apply<8>(mask_take(mr), in);                                    // d pre_0
+        tiles_store<8>(grad_row, in);
+        ws_rewind(ws, P.w0, lds_all, lane);
+    }
+}
+
 extern "C" size_t swnerf_packed_bwd_floats(void) { return (size_t)SW_BWD_FLOATS; }
 extern "C" size_t swnerf_act_floats_per_row(void) { return (size_t)SW_ACT_LD; }
 extern "C" size_t swnerf_mask_floats(int64_t M) { return M <= 0 ? 0 : (size_t)((M + 31) / 32) * SW_MASK_TILE_FLOATS; }
@@ -280,4 +433,62 @@ extern "C" int swnerf_deform_forward_train(const float* packed, const float* x, 
     const dim3 grid((unsigned)((M + 127) / 128)), block(256);
     hipLaunchKernelGGL(deform_forward_train_kernel, grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "deform_forward_train launch");
+}
+
+// ---- the fused training pass ("backward for the fused path") ---------------------
+extern "C" int64_t swnerf_train_rows(int64_t n_rays, int n_samples) { return n_rays * (int64_t)((n_samples + 31) / 32) * 32; }
+extern "C" int swnerf_xs_floats_per_row(void) { return SW_XS_LD; }
+
+extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act, float* bits, float* xs, void* stream) {
+    if (!args) return sw_fail(SWNERF_E_ARG, "render_pass_train: NULL args");
+    const swnerf_pass_args& a = *args;
+    if (a.n_rays == 0 && a.packed) return 0;
+    if (!a.packed || !a.ray_batch || !act || !bits || !xs) return sw_fail(SWNERF_E_ARG, "render_pass_train: NULL pointer");
+    if (a.kind != SWNERF_NET_CANON || a.cols != 11) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: the static net with an 11-column ray batch only");
+    if (a.n_rays < 0 || a.n_samples < 2 || a.n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: 2 <= n_samples <= %d (got %d)", PB_SMAX, a.n_samples);
+    if (!a.raw || !(a.z_vals || a.z_out)) return sw_fail(SWNERF_E_ARG, "render_pass_train: the backward needs raw and the depths (z_vals given or z_out)");
+    if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: embedder bands (%d,%d) exceed (10,4)", a.L_pos, a.L_dir);
+    if (a.z_vals && a.t_rand) return sw_fail(SWNERF_E_ARG, "render_pass_train: t_rand only applies to coarse sampling");
+    if (a.dx) return sw_fail(SWNERF_E_ARG, "render_pass_train: no dx output (static net)");
+    PassDev P;
+    P.a = a;
+    int rc = stream_ptrs(a.kind, a.packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
+    if (rc) return rc;
+    P.act = act; P.bits = bits; P.xs = xs;
+    P.sort_n = 0; P.sort_s = 0;
+    size_t lds = PassLds<true>::FIXED * sizeof(float);
+    if (a.n_importance > 0) {
+        if (!a.z_fine) return sw_fail(SWNERF_E_ARG, "render_pass_train: n_importance>0 needs z_fine");
+        if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
+            return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: resampling supports 3<=N_samples<=%d and N_samples+N_importance<=%d", SW_LDS_SC, SW_LDS_SORT);
+        int p2 = 2;
+        while (p2 < a.n_importance) p2 <<= 1;
+        P.sort_n = p2;
+        p2 = 2;
+        while (p2 < a.n_samples) p2 <<= 1;
+        P.sort_s = p2;
+        lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
+    }
+    const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
+    hipLaunchKernelGGL((render_pass_kernel<false, true>), grid, block, lds, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "render_pass_train launch");
+}
+
+extern "C" int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, const float* raw, const float* z_vals,
+                                           const float* ray_batch, int cols, const float* noise, int64_t n_rays, int n_samples,
+                                           int white_bkgd, const float* g_rgb, const float* g_disp, const float* g_acc,
+                                           float* grad, float* d_raw, void* stream) {
+    if (n_rays == 0 && packed_bwd) return 0;
+    if (!packed_bwd || !bits || !raw || !z_vals || !ray_batch || !grad || !d_raw || n_rays < 0)
+        return sw_fail(SWNERF_E_ARG, "render_pass_backward: NULL pointer or negative n_rays");
+    if (n_samples < 2 || n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_backward: 2 <= n_samples <= %d (got %d)", PB_SMAX, n_samples);
+    if (cols < 8) return sw_fail(SWNERF_E_ARG, "render_pass_backward: ray_batch needs >= 8 columns");
+    PassBwdDev P;
+    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_BWD_W_FLOATS; P.bits = bits; P.raw = raw; P.z = z_vals; P.ray_batch = ray_batch;
+    P.cols = cols; P.noise = noise; P.n_rays = n_rays; P.S = n_samples; P.white = white_bkgd;
+    P.g_rgb = g_rgb; P.g_disp = g_disp; P.g_acc = g_acc; P.grad = grad; P.d_raw = d_raw;
+    const size_t lds = (SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    hipLaunchKernelGGL(render_pass_backward_kernel, grid, block, lds, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "render_pass_backward launch");
 }

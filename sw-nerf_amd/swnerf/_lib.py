@@ -16,7 +16,8 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
            "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
-           "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx"]
+           "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
+           "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad"]
 BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM = 0, 1, 2
 
 
@@ -91,12 +92,19 @@ def lib():
     L.swnerf_deform_forward_train.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_mlp_backward_dx_pts.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
     L.swnerf_deform_backward_dx.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    L.swnerf_train_rows.restype = c_int64
+    L.swnerf_train_rows.argtypes = [c_int64, c_int]
+    L.swnerf_xs_floats_per_row.argtypes = []
+    L.swnerf_render_pass_train.argtypes = [POINTER(PassArgs), c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_render_pass_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_unslot_grad.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
-                        "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats"):
+                        "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 101:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 101 - rebuild it "
+    if L.swnerf_version() != 102:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 102 - rebuild it "
                            "(python __graft_entry__.py)")
     _lib = L
     return L

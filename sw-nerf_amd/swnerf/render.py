@@ -76,11 +76,17 @@ def closure_embedders(network_query_fn):
     return {k: names[k] for k in ("embed_fn", "embeddirs_fn", "embedtime_fn") if k in names}
 
 
-def fused_plan(network_query_fn, nets, need_time=False):
+def wants_grad(nets):
+    return torch.is_grad_enabled() and any(p.requires_grad for net in nets if isinstance(net, torch.nn.Module) for p in net.parameters())
+
+
+def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
     """Returns (L_pos, L_dir, L_time) when every net is a swnerf module on the GPU and the
-    closure's encoders are the standard ones matching the nets' input sizes; else None."""
-    if torch.is_grad_enabled() and any(p.requires_grad for net in nets if isinstance(net, torch.nn.Module) for p in net.parameters()):
-        return None          # training: the differentiable op path (the fused pass has no backward yet)
+    closure's encoders are the standard ones matching the nets' input sizes; else None.
+    Under autograd only callers that have a backward for the fused pass (allow_train: the static render_rays) get a
+    plan; everything else takes the differentiable op path."""
+    if wants_grad(nets) and not allow_train:
+        return None
     emb = closure_embedders(network_query_fn)
     ef, edf, etf = emb.get("embed_fn"), emb.get("embeddirs_fn"), emb.get("embedtime_fn")
     if not (isinstance(ef, EmbedFn) and isinstance(edf, EmbedFn) and ef.input_dims == 3 and edf.input_dims == 3):
@@ -141,6 +147,101 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
     return out
 
 
+class _FusedPassTrain(torch.autograd.Function):
+    """The fused render pass under autograd (the reference's step is render -> img2mse ->
+    loss.backward(), nerf/run.py:684-708).  forward = swnerf_render_pass_train: the inference pass that also saves
+    activations, ReLU masks, the encodings and raw; backward = swnerf_render_pass_backward (one wave per ray: compositing
+    backward in LDS, then the dX chain per tile) + one TN MFMA GEMM per Linear layer.  No [M,90] embedding, no cat, no
+    pts tensor ever reaches HBM.  Gradients flow to the net's parameters only (rays are data; the depths of the fine
+    pass are detached in the reference, nerf/run.py:398)."""
+
+    @staticmethod
+    def forward(ctx, net, rb, z_vals, S, lindisp, t_rand, noise, white_bkgd, n_importance, u, *params):
+        from .model import _zero_grads  # noqa: F401
+        kind, packed, Lp, Ld, _ = net.packed()
+        L = _lib.lib()
+        N, cols = rb.shape
+        dev = rb.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        rows = L.swnerf_train_rows(N, S)
+        act, bits, xs = new(rows, L.swnerf_act_floats_per_row()), new(L.swnerf_mask_floats(rows)), new(rows, L.swnerf_xs_floats_per_row())
+        raw, rgb, disp, acc = new(N, S, 4), new(N, 3), new(N), new(N)
+        a = _lib.PassArgs()
+        a.ray_batch, a.n_rays, a.cols, a.kind, a.packed = rb.data_ptr(), N, cols, kind, packed.data_ptr()
+        a.run_deform, a.L_pos, a.L_dir, a.L_time, a.n_samples = 0, Lp, Ld, 0, S
+        a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+        a.rgb_map, a.disp_map, a.acc_map, a.raw = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), raw.data_ptr()
+        if z_vals is not None:
+            z = z_vals
+            a.z_vals = z.data_ptr()
+        else:
+            z = new(N, S)
+            a.z_out = z.data_ptr()
+        for name, t in (("t_rand", t_rand), ("noise", noise), ("u", u)):
+            if t is not None:
+                setattr(a, name, t.data_ptr())
+        a.n_importance = int(n_importance)
+        if n_importance > 0:
+            z_fine, z_std = new(N, S + int(n_importance)), new(N)
+            a.z_fine, a.z_std = z_fine.data_ptr(), z_std.data_ptr()
+        else:
+            z_fine, z_std = new(0), new(0)
+        if PASS_HOOK is not None:
+            PASS_HOOK("begin", N, S)
+        _lib.check(L.swnerf_render_pass_train(a, _lib.ptr(act), _lib.ptr(bits), _lib.ptr(xs), _lib.stream_of(rb)), "render_pass_train")
+        if PASS_HOOK is not None:
+            PASS_HOOK("end", N, S)
+        ctx.net, ctx.S, ctx.white, ctx.bands = net, S, bool(white_bkgd), (Lp, Ld)
+        ctx.has_noise = noise is not None
+        ctx.save_for_backward(rb, z, raw, act, bits, xs, noise if noise is not None else new(0), *params)
+        ctx.mark_non_differentiable(z_fine, z_std)
+        return rgb, disp, acc, z_fine, z_std
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs):
+        from .model import _zero_grads, _canon_weight_grads_slots
+        rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
+        net, S = ctx.net, ctx.S
+        Lp, Ld = ctx.bands
+        L = _lib.lib()
+        N, cols = rb.shape
+        rows = act.shape[0]
+        st = _lib.stream_of(rb)
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_rgb, g_disp, g_acc = c(g_rgb), c(g_disp), c(g_acc)
+        grad = torch.empty_like(act)
+        d_raw = torch.empty((rows, 4), dtype=torch.float32, device=rb.device)
+        _lib.check(L.swnerf_render_pass_backward(_lib.ptr(net.packed_bwd()), _lib.ptr(bits), _lib.ptr(raw), _lib.ptr(z), _lib.ptr(rb), cols,
+                                                 _lib.ptr(noise) if ctx.has_noise else None, N, S, int(ctx.white), _lib.ptr(g_rgb),
+                                                 _lib.ptr(g_disp), _lib.ptr(g_acc), _lib.ptr(grad), _lib.ptr(d_raw), st), "render_pass_backward")
+        g = _zero_grads(params)
+        _canon_weight_grads_slots(L, st, rows, grad, act, xs, d_raw, net.input_ch, net.input_ch_views, Lp, Ld, g)
+        return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
+
+
+def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
+                      n_importance=0, u=None):
+    """One differentiable fused pass (`_FusedPassTrain`): dict with rgb_map disp_map acc_map (+ z_fine z_std)."""
+    from .model import _CANON_ORDER
+    rb = _lib.dev_f32(ray_batch.detach(), "ray_batch")
+    N, S = rb.shape[0], int(n_samples)
+    chk = lambda t, name, last: None if t is None else _lib.dev_f32(t.detach(), name, last)
+    z_vals, t_rand, noise, u = chk(z_vals, "z_vals", S), chk(t_rand, "t_rand", S), chk(noise, "noise", S), chk(u, "u", int(n_importance))
+    for name, t in (("z_vals", z_vals), ("t_rand", t_rand), ("noise", noise), ("u", u)):
+        if t is not None and t.shape[0] != N:
+            raise ValueError(f"swnerf.render_pass_train: {name} must have {N} rows, got {tuple(t.shape)}")
+    sd = dict(net.named_parameters())
+    rgb, disp, acc, z_fine, z_std = _FusedPassTrain.apply(net, rb, z_vals, S, bool(lindisp), t_rand, noise, bool(white_bkgd),
+                                                          int(n_importance), u, *[sd[n] for n in _CANON_ORDER])
+    out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc}
+    if n_importance > 0:
+        out["z_fine"], out["z_std"] = z_fine, z_std
+    return out
+
+
+TRAIN_FUSED_MAX_SAMPLES = 256      # include/swnerf.h: swnerf_render_pass_train
+
+
 def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev):
     """The three random tensors of render_rays (nerf/run.py:375-381, ray.py:117-132, :176-184)."""
     t_rand = u = None
@@ -168,12 +269,31 @@ def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev)
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
     """nerf/run.py:316-422."""
-    plan = fused_plan(network_query_fn, [network_fn, network_fine]) if ray_batch.shape[-1] == 11 else None
+    plan = fused_plan(network_query_fn, [network_fn, network_fine], allow_train=True) if ray_batch.shape[-1] == 11 else None
+    training = wants_grad([network_fn, network_fine])
+    if plan is not None and training:
+        # the fused pass has a backward for the static nets, up to 256 samples per pass, when `raw` is not asked for
+        # (a returned raw would need a gradient path of its own); anything else trains on the differentiable op path
+        ok = (not retraw and ray_batch.shape[0] > 0 and N_samples <= TRAIN_FUSED_MAX_SAMPLES
+              and N_samples + max(0, N_importance) <= TRAIN_FUSED_MAX_SAMPLES and os.environ.get("SWNERF_TRAIN_OP_PATH") != "1"
+              and all(net is None or isinstance(net, vallina_NeRF) for net in (network_fn, network_fine)))
+        if not ok:
+            plan = None
     if plan is None:
         return _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb,
                                     N_importance, network_fine, white_bkgd, raw_noise_std, pytest)
     N = ray_batch.shape[0]
     t_rand, u, noise = _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
+    if training:
+        p0 = render_pass_train(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
+                               white_bkgd=white_bkgd, n_importance=max(0, N_importance), u=u)
+        if N_importance <= 0:
+            return {'rgb_map': p0["rgb_map"], 'disp_map': p0["disp_map"], 'acc_map': p0["acc_map"]}
+        S1 = N_samples + N_importance
+        run_fn = network_fn if network_fine is None else network_fine
+        p1 = render_pass_train(ray_batch, run_fn, S1, z_vals=p0["z_fine"], noise=noise(S1), white_bkgd=white_bkgd)
+        return {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"],
+                'rgb0': p0["rgb_map"], 'disp0': p0["disp_map"], 'acc0': p0["acc_map"], 'z_std': p0["z_std"]}
     want = ["rgb_map", "disp_map", "acc_map"] + (["raw"] if (retraw and N_importance <= 0) else [])
     p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
                      white_bkgd=white_bkgd, want=want, n_importance=max(0, N_importance), u=u)

@@ -34,3 +34,18 @@ with torch.no_grad():
         e1.record()
         torch.cuda.synchronize()
         print(f"| {S} | {S // 32} | {e0.elapsed_time(e1) / 20:.4f} |")
+
+    print("\n| coarse form (depths computed in the kernel), 64 samples | ms per launch (4096 rays) |")
+    print("|---|---|")
+    for name, kw in (("no resampling", dict()), ("+ sample_pdf/merge, 128 fine samples", dict(n_importance=128)),
+                     ("+ the same with random u (sort-first branch)", dict(n_importance=128, u=torch.rand((4096, 128), device=dev)))):
+        f = lambda: render.render_pass(rb, net, 64, white_bkgd=True, **kw)
+        f(); f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"| {name} | {e0.elapsed_time(e1) / 20:.4f} |")
