@@ -55,14 +55,17 @@ def test_mfma_kernels_isa(asm):
             steps = 96 + 256 + 64
         if "deform_backward_dx" in name:           # the _time.7 .. _time.1 loop body
             steps = 256
+        if "render_pass_backward" in name:         # the fused backward: the same chain as mlp_backward_dx<false>, per tile
+            steps = 16 + 128 + 256 + 256
         # the backward chains also fetch the ReLU bit masks by LDS-DMA: one fetch before the ring is primed, one per
         # static use site after it (mlp_backward_dx: views hidden, h7, loop body; deformation: h7, loop body)
-        masks = 3 if "mlp_backward_dx" in name else (2 if "deform_backward_dx" in name else 0)
+        masks = 3 if ("mlp_backward_dx" in name or "render_pass_backward" in name) else (2 if "deform_backward_dx" in name else 0)
         assert stats["mfma"] == 4 * steps, (name, stats)
         # ring priming: 8 steps in the render unit, 16 in the training unit (train_kernels.hip)
-        training = any(k in name for k in ("mlp_backward_dx", "deform_", "mlp_forward_kernelILb0ELb1E"))
+        training = any(k in name for k in ("mlp_backward_dx", "deform_", "mlp_forward_kernelILb0ELb1E", "render_pass_backward",
+                                           "render_pass_kernelILb0ELb1E"))
         assert dma == steps + (16 if training else 8) + masks, (name, dma)
-    assert len(seen) == 10
+    assert len(seen) == 12
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)
         assert m, name
@@ -71,7 +74,7 @@ def test_mfma_kernels_isa(asm):
         # A scratch access shares vmcnt with the weight DMA ring, so a reload inside a segment would drain the ring:
         # should spills ever come back, none may sit within 40 instructions of an MFMA.
         assert priv == 0, f"{name} spills {priv} bytes/lane to scratch"
-        if "render_pass_kernel" in name or "query_points" in name or "mlp_backward_dx" in name:
+        if "render_pass" in name or "query_points" in name or "mlp_backward_dx" in name:
             body = asm[asm.index("\n" + name + ":"):]
             body = body[:body.index("s_endpgm")]
             lines = [l for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
