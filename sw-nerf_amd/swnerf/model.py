@@ -91,13 +91,19 @@ def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
     mm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
 
 
-def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, Lp, Ld, g):
-    """The same 12 weight gradients for the FUSED training pass: the encodings come as xs [M, 96] in operand slot
-    order (64 slots gamma(x), 32 slots gamma(d); csrc/swnerf_common.h sw_xs_col), so the three GEMMs against them
-    produce slot-ordered columns that swnerf_unslot_grad moves to their reference columns.  Every operand is 16-byte
-    aligned here (x[:, :63] with ld 90 was not)."""
-    slots = torch.zeros(256 * 64 + 256 * 64 + 128 * 32, dtype=torch.float32, device=grad.device)
-    c0s, c5s, cvs = slots[:16384].view(256, 64), slots[16384:32768].view(256, 64), slots[32768:].view(128, 32)
+def _slot_buffers(device):
+    """Zeroed slot-ordered accumulators for the three encoding GEMMs of the fused training pass."""
+    slots = torch.zeros(256 * 64 + 256 * 64 + 128 * 32, dtype=torch.float32, device=device)
+    return slots[:16384].view(256, 64), slots[16384:32768].view(256, 64), slots[32768:].view(128, 32)
+
+
+def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slot_bufs):
+    """The same 12 weight gradients for the FUSED training pass (accumulating: call once per row chunk): the
+    encodings come as xs [M, 96] in operand slot order (64 slots gamma(x), 32 slots gamma(d); csrc/swnerf_common.h
+    sw_xs_col), so the three GEMMs against them accumulate slot-ordered columns into `slot_bufs`, which
+    _unslot_weight_grads moves to their reference columns at the end.  Every operand is 16-byte aligned here
+    (x[:, :63] with ld 90 was not)."""
+    c0s, c5s, cvs = slot_bufs
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
     mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
     for l in (1, 2, 3, 4, 6, 7):
@@ -107,6 +113,10 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, Lp, Ld
     mm(grad, 2304, 128, xs, 64, 32, cvs, 0, None)
     _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
     mm(d_out, 0, 3, act, 2304, 128, g[22], 0, g[23])                           # rgb_linear
+
+
+def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g):
+    c0s, c5s, cvs = slot_bufs
     for cs, nslots, slot0, W, col0 in ((c0s, 64, 0, g[0], 0), (c5s, 64, 0, g[10], 0), (cvs, 32, 64, g[16], 256)):
         _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), cs.stride(0), cs.shape[0], slot0, nslots, Lp, Ld, W.data_ptr(), W.stride(0),
                                         col0, st), "unslot_grad")

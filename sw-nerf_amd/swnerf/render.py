@@ -199,23 +199,38 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs):
-        from .model import _zero_grads, _canon_weight_grads_slots
+        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
         L = _lib.lib()
         N, cols = rb.shape
-        rows = act.shape[0]
         st = _lib.stream_of(rb)
         c = lambda g: None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_acc = c(g_rgb), c(g_disp), c(g_acc)
-        grad = torch.empty_like(act)
-        d_raw = torch.empty((rows, 4), dtype=torch.float32, device=rb.device)
-        _lib.check(L.swnerf_render_pass_backward(_lib.ptr(net.packed_bwd()), _lib.ptr(bits), _lib.ptr(raw), _lib.ptr(z), _lib.ptr(rb), cols,
-                                                 _lib.ptr(noise) if ctx.has_noise else None, N, S, int(ctx.white), _lib.ptr(g_rgb),
-                                                 _lib.ptr(g_disp), _lib.ptr(g_acc), _lib.ptr(grad), _lib.ptr(d_raw), st), "render_pass_backward")
         g = _zero_grads(params)
-        _canon_weight_grads_slots(L, st, rows, grad, act, xs, d_raw, net.input_ch, net.input_ch_views, Lp, Ld, g)
+        slot_bufs = _slot_buffers(rb.device)
+        # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
+        # it run per CHUNK of rays, so only one chunk of it is ever alive (GEMMs accumulate: C += A^T.B).  A chunk is
+        # still >= 196 608 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
+        rows_per_ray = act.shape[0] // N
+        chunk = max(4, (TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
+        packed_bwd = net.packed_bwd()
+        mask_per_ray = bits.numel() // N
+        sl = lambda t, r0, r1: None if t is None else t[r0:r1]
+        grad = torch.empty((min(N, chunk) * rows_per_ray, act.shape[1]), dtype=torch.float32, device=rb.device)
+        d_raw = torch.empty((min(N, chunk) * rows_per_ray, 4), dtype=torch.float32, device=rb.device)
+        for r0 in range(0, N, chunk):
+            r1 = min(N, r0 + chunk)
+            n, m = r1 - r0, (r1 - r0) * rows_per_ray
+            _lib.check(L.swnerf_render_pass_backward(
+                _lib.ptr(packed_bwd), _lib.ptr(bits[r0 * mask_per_ray:r1 * mask_per_ray]), _lib.ptr(raw[r0:r1]), _lib.ptr(z[r0:r1]),
+                _lib.ptr(rb[r0:r1]), cols, _lib.ptr(noise[r0:r1]) if ctx.has_noise else None, n, S, int(ctx.white),
+                _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(grad), _lib.ptr(d_raw), st),
+                "render_pass_backward")
+            a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
+            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs)
+        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
@@ -240,6 +255,7 @@ def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, 
 
 
 TRAIN_FUSED_MAX_SAMPLES = 256      # include/swnerf.h: swnerf_render_pass_train
+TRAIN_BWD_CHUNK_ROWS = 196608      # rows of the gradient buffer alive at once in the fused backward (1.9 GB)
 
 
 def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev):

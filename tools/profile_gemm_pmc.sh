@@ -8,3 +8,6 @@ run() { name=$1; shift
 run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES && \
 run waits SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE && \
 run insts SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES
+python3 tools/summarize_pmc_any.py $OUT gemm_tn > $OUT/summary.md
+find $OUT -name '*.csv' -size +2M -delete
+cat $OUT/summary.md
