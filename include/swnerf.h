@@ -264,6 +264,18 @@ int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, cons
 int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nslots, int L_pos, int L_dir,
                        float* W, int ldw, int col0, void* stream);
 
+/* ---- any-shape MLP layers (model.py:10-62, 93-151, 227-296 at shapes the fused kernels are not built for:
+ * use_viewdirs=False - the reference's argparse default, utils.py:26-29 / model.py:59-60 -, other D / W / skips) -------
+ * linear   : y[M,N] = act(x[M,K] . weight[N,K]^T + bias)   torch.nn.functional.linear (+ relu if relu != 0); bias may be NULL
+ * gemm_nn  : c[M,N] = a[M,K] . b[K,N]                       input gradient of a linear layer: dX = dY . weight
+ * relu_mask: dy[e] = y[e] > 0 ? dy[e] : 0, in place        relu backward
+ * The weight gradient is swnerf_gemm_tn.  Any leading dimensions >= the row length; fp32 MFMA, fp32 accumulate. */
+int swnerf_linear(const float* x, int ldx, int64_t M, int K, const float* weight /*[N,K]*/, const float* bias /*[N]*/,
+                  int N, int relu, float* y, int ldy, void* stream);
+int swnerf_gemm_nn(const float* a, int lda, int64_t M, int K, const float* b, int ldb, int N, float* c, int ldc,
+                   void* stream);
+int swnerf_relu_mask(float* dy, const float* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

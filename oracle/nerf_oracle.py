@@ -326,3 +326,67 @@ def make_ray_batch(rays_o, rays_d, near, far, frame_time=None, ndc=False, H=None
 
 def to_torch_sd(sd_np):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+
+
+# ---------------------------------------------------------------- any-shape nets (test infrastructure, like the rest)
+def generic_mlp(sd, x, D, skips, input_ch, input_ch_views, use_viewdirs, prefix=""):
+    """vallina_NeRF.forward / NeRFOriginal.forward (model.py:39-62, 273-296) for ANY D, W, skips, use_viewdirs
+    (use_viewdirs=False: outputs = output_linear(h), model.py:59-60)."""
+    pts, views = torch.split(x, [input_ch, input_ch_views], dim=-1)
+    h = pts
+    for i in range(D):
+        h = F.relu(_lin(sd, f"{prefix}pts_linears.{i}", h))
+        if i in skips:
+            h = torch.cat([pts, h], -1)
+    if not use_viewdirs:
+        return _lin(sd, f"{prefix}output_linear", h)
+    sigma = _lin(sd, f"{prefix}alpha_linear", h)
+    feat = _lin(sd, f"{prefix}feature_linear", h)
+    h = F.relu(_lin(sd, f"{prefix}views_linears.0", torch.cat([feat, views], -1)))
+    return torch.cat([_lin(sd, f"{prefix}rgb_linear", h), sigma], -1)
+
+
+def generic_dnerf_mlp(sd, x, t_emb, D, skips, input_ch, input_ch_views, use_viewdirs, multires=10, zero_canonical=True):
+    """DirectTemporalNeRF.forward (model.py:128-151) for any D, W, skips."""
+    pts, views = torch.split(x, [input_ch, input_ch_views], dim=-1)
+    if float(t_emb[0, 0]) == 0. and zero_canonical:
+        dx = torch.zeros_like(pts[:, :3])
+    else:
+        h = torch.cat([pts, t_emb], -1)
+        for i in range(D):
+            h = F.relu(_lin(sd, f"_time.{i}", h))
+            if i in skips:
+                h = torch.cat([pts, h], -1)
+        dx = _lin(sd, "_time_out", h)
+        pts = embed(pts[:, :3] + dx, multires)
+    return generic_mlp(sd, torch.cat([pts, views], -1), D, skips, input_ch, input_ch_views, use_viewdirs, prefix="_occ."), dx
+
+
+def render_rays_generic(ray_batch, net_fn, N_samples, N_importance=0, white_bkgd=False, multires=10, multires_views=4):
+    """render_rays (nerf/run.py:316-422) with ONE net given as a callable embedded-rows -> raw (any output_ch >= 4), with or
+    without view directions (ray_batch 11 or 8 columns), perturb = 0."""
+    N = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+
+    def query(pts):
+        e = embed(pts.reshape(-1, 3), multires)
+        if viewdirs is not None:
+            e = torch.cat([e, embed(viewdirs[:, None].expand(pts.shape).reshape(-1, 3), multires_views)], -1)
+        raw = net_fn(e)
+        return raw.reshape(N, -1, raw.shape[-1])
+
+    z = coarse_z(near, far, N_samples)
+    raw = query(rays_o[:, None] + rays_d[:, None] * z[..., None])
+    rgb, disp, acc, w, _ = raw2outputs(raw[..., :4], z, rays_d, 0., white_bkgd)
+    ret = {}
+    if N_importance > 0:
+        ret.update(rgb0=rgb, disp0=disp, acc0=acc)
+        zs = sample_pdf(.5 * (z[:, 1:] + z[:, :-1]), w[:, 1:-1], N_importance, det=True)
+        z, _ = torch.sort(torch.cat([z, zs], -1), -1)
+        raw = query(rays_o[:, None] + rays_d[:, None] * z[..., None])
+        rgb, disp, acc, w, _ = raw2outputs(raw[..., :4], z, rays_d, 0., white_bkgd)
+        ret["z_std"] = torch.std(zs, dim=-1, unbiased=False)
+    ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
+    return ret

@@ -17,7 +17,8 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
-           "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad"]
+           "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
+           "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask"]
 BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM = 0, 1, 2
 
 
@@ -99,6 +100,9 @@ def lib():
     L.swnerf_render_pass_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_unslot_grad.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
+    L.swnerf_linear.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
+    L.swnerf_gemm_nn.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
+    L.swnerf_relu_mask.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
                         "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):

@@ -4,8 +4,10 @@ reference's checkpoints `network_fn_state_dict` / `network_fine_state_dict` load
 nerf/run.py:269-280), whose forward runs the register-resident MFMA kernel
 (csrc/mlp_core.h) through `swnerf_mlp_forward`.
 
-Built configuration = the one every shipped config uses: D=8, W=256, skips=[4],
-use_viewdirs=True.  Anything else constructs (state_dict parity) but raises at forward.
+The register-resident kernel is built for the configuration every shipped config uses: D=8, W=256, skips=[4],
+use_viewdirs=True with get_embedder-sized inputs.  Any other shape (use_viewdirs=False - the reference's argparse
+default -, other D / W / skips / input sizes) runs layer by layer on the generic MFMA GEMM kernels (swnerf/generic.py,
+csrc/generic_kernels.hip): slower, same results, differentiable.
 TNeRF (model.py:152-210) is out of scope.
 Training: with grad enabled, forward saves the activations and backward runs the
 register-resident dX chain + TN MFMA GEMMs (`_MlpTrain`, `_DnerfTrain`); gradients w.r.t. the embedded inputs are
@@ -275,6 +277,15 @@ class _PackedMixin:
         out = _MlpTrain.apply(self, flat, *[sd[n] for n in names[:24]])
         return out.reshape(*lead, 4)
 
+    def _is_fused_arch(self):
+        """True for the shape the register-resident kernels are built for; anything else runs layer by layer on the
+        generic GEMM kernels (swnerf/generic.py)."""
+        try:
+            self._pack_params()
+            return True
+        except NotImplementedError:
+            return False
+
     def _check_arch(self):
         if not (self.D == 8 and self.W == 256 and list(self.skips) == [4] and self.use_viewdirs):
             raise NotImplementedError(
@@ -352,6 +363,9 @@ class vallina_NeRF(nn.Module, _PackedMixin):
         return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
 
     def forward(self, x):
+        if not self._is_fused_arch():
+            from .generic import canonical_forward
+            return canonical_forward(self, x)
         if self._wants_grad():
             return self._forward_train(x)
         return self._forward_hip(x)[0]
@@ -378,6 +392,9 @@ class NeRFOriginal(nn.Module, _PackedMixin):
         return _lib.NET_CANON, _CANON_ORDER, Lp, Ld, 0
 
     def forward(self, x, ts):
+        if not self._is_fused_arch():
+            from .generic import canonical_forward
+            return canonical_forward(self, x), torch.zeros_like(x[..., :3])
         out = self._forward_train(x) if self._wants_grad() else self._forward_hip(x)[0]
         return out, torch.zeros_like(x[..., :3])
 
@@ -415,6 +432,9 @@ class DirectTemporalNeRF(nn.Module, _PackedMixin):
         return _lib.NET_DNERF, ["_occ." + n for n in _CANON_ORDER] + _DEFORM_ORDER, Lp, Ld, Lt
 
     def forward(self, x, ts):
+        if not self._is_fused_arch():
+            from .generic import temporal_forward
+            return temporal_forward(self, x, ts)
         t = ts[0]
         # the reference asserts one unique time and branches on its value: two host syncs
         # (model.py:141-144); one here

@@ -139,6 +139,8 @@ class _Raw2Outputs(torch.autograd.Function):
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None):
     """ray.py:155-198 -> (rgb_map, disp_map, acc_map, weights, depth_map).
     `noise` (extra, optional) injects the density noise instead of torch.randn * raw_noise_std."""
+    if isinstance(raw, torch.Tensor) and raw.shape[-1] > 4:
+        raw = raw[..., :4]              # output_ch = 5 (use_viewdirs=False with N_importance > 0, nerf/run.py:231): channels 0..3 are read
     raw = _lib.dev_f32(raw, "raw", 4)
     z_vals = _lib.dev_f32(z_vals, "z_vals")
     rays_d = _lib.dev_f32(rays_d, "rays_d", 3)

@@ -97,8 +97,8 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
     for net in nets:
         if net is None:
             continue
-        if not isinstance(net, (vallina_NeRF, NeRFOriginal, DirectTemporalNeRF)):
-            return None
+        if not isinstance(net, (vallina_NeRF, NeRFOriginal, DirectTemporalNeRF)) or not net._is_fused_arch():
+            return None          # foreign modules and shapes the fused kernel is not built for: the op path
         if net.input_ch != ef.out_dim or net.input_ch_views != edf.out_dim:
             return None
         if isinstance(net, DirectTemporalNeRF) and (not need_time or net.input_ch_time != etf.out_dim):
@@ -212,7 +212,7 @@ class _FusedPassTrain(torch.autograd.Function):
         slot_bufs = _slot_buffers(rb.device)
         # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
         # it run per CHUNK of rays, so only one chunk of it is ever alive (GEMMs accumulate: C += A^T.B).  A chunk is
-        # still >= 196 608 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
+        # 393 216 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
         rows_per_ray = act.shape[0] // N
         chunk = max(4, (TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
         packed_bwd = net.packed_bwd()
@@ -255,7 +255,8 @@ def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, 
 
 
 TRAIN_FUSED_MAX_SAMPLES = 256      # include/swnerf.h: swnerf_render_pass_train
-TRAIN_BWD_CHUNK_ROWS = 196608      # rows of the gradient buffer alive at once in the fused backward (1.9 GB)
+TRAIN_BWD_CHUNK_ROWS = 393216      # rows of the gradient buffer alive at once in the fused backward (3.8 GB); each chunk costs one
+                                   # atomic epilogue per GEMM (~44 us), so not smaller than needed
 
 
 def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev):
@@ -427,8 +428,6 @@ def pack_ray_batch(rays_o, rays_d, near, far, frame_time=None, ndc=False, H=0, W
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
     """nerf/run.py:105-169 -> [rgb_map, disp_map, acc_map, extras]."""
-    if not use_viewdirs:
-        raise NotImplementedError("swnerf.render: only use_viewdirs=True is built (every shipped config sets it)")
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
     else:
@@ -444,6 +443,8 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
         rb[:, -3:] = vb[:, -3:]
     else:
         rb = pack_ray_batch(rays_o, rays_d, near, far, ndc=ndc, H=H, W=W, focal=K[0][0])
+    if not use_viewdirs:
+        rb = rb[:, :8].contiguous()          # rays = cat[o, d, near, far] without view directions (nerf/run.py:152-157)
     all_ret = batchify_rays(rb, chunk, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))

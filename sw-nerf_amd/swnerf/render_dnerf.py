@@ -192,8 +192,6 @@ def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
 def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., frame_time=None,
            use_viewdirs=False, c2w_staticcam=None, **kwargs):
     """d_nerf/run_dnerf.py:104-173 -> [rgb_map, disp_map, acc_map, extras]."""
-    if not use_viewdirs:
-        raise NotImplementedError("swnerf.render_dnerf.render: only use_viewdirs=True is built")
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, float(focal), c2w)
     else:
@@ -206,6 +204,8 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
     rb = pack_ray_batch(rays_o, rays_d, near, far, frame_time=ft, ndc=ndc, H=H, W=W, focal=focal)
     if c2w_staticcam is not None:
         rb[:, -3:] = pack_ray_batch(rays_o, viewsrc, near, far)[:, -3:]
+    if not use_viewdirs:
+        rb = rb[:, :9].contiguous()          # rays = cat[o, d, near, far, frame_time] (run_dnerf.py:153-159)
     key = rb.untyped_storage().data_ptr()
     if isinstance(ft, float):
         _TIME_HINT[key] = ft

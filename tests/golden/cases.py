@@ -187,3 +187,63 @@ def g9_blender_frames():
 # ------------------------------------------------------------------ G10 mesh grid query
 G10_BOUNDS = [(-1., 1.), (-1., 2.), (-4., 2.)]          # nerf/extract_mesh.py:148
 G10_RES, G10_VIEWS = 6, 8
+
+
+# ------------------------------------------------------------------ G11 any-shape nets (model.py:59-60, utils.py:26-29)
+def generic_state_dict(seed, D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, prefix="", alpha_bias=0.0):
+    """Seeded weights with the reference's parameter names / shapes for ANY (D, W, skips, use_viewdirs) of
+    vallina_NeRF / NeRFOriginal (model.py:22-37, 251-269): He-normal weights, small biases."""
+    rng = np.random.default_rng(seed)
+    he = lambda o, i: (rng.standard_normal((o, i)) * np.sqrt(2.0 / max(i, 1))).astype(np.float32)
+    bias = lambda o: (rng.standard_normal(o) * 0.05).astype(np.float32)
+    sd = {}
+    ins = [input_ch] + [W + input_ch if i in skips else W for i in range(D - 1)]
+    for i, k in enumerate(ins):
+        sd[f"{prefix}pts_linears.{i}.weight"], sd[f"{prefix}pts_linears.{i}.bias"] = he(W, k), bias(W)
+    sd[f"{prefix}views_linears.0.weight"], sd[f"{prefix}views_linears.0.bias"] = he(W // 2, W + input_ch_views), bias(W // 2)
+    if use_viewdirs:
+        sd[f"{prefix}feature_linear.weight"], sd[f"{prefix}feature_linear.bias"] = he(W, W), bias(W)
+        sd[f"{prefix}alpha_linear.weight"], sd[f"{prefix}alpha_linear.bias"] = he(1, W), np.full((1,), alpha_bias, np.float32)
+        sd[f"{prefix}rgb_linear.weight"], sd[f"{prefix}rgb_linear.bias"] = he(3, W // 2), bias(3)
+    else:
+        sd[f"{prefix}output_linear.weight"], sd[f"{prefix}output_linear.bias"] = he(output_ch, W), bias(output_ch)
+        sd[f"{prefix}output_linear.bias"][3] = alpha_bias
+    return sd
+
+
+# (name, kwargs): the shapes G11 covers.  novd = what `--use_viewdirs` unset gives (nerf/run.py:226-231: input_ch_views
+# = 0, output_ch = 5 with N_importance > 0); small = another depth / width / skip set; the D-NeRF pair at D=4, W=64.
+G11_NETS = {
+    "novd": dict(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False),
+    "small": dict(D=4, W=128, input_ch=63, input_ch_views=27, output_ch=5, skips=[2], use_viewdirs=True),
+    "tiny_novd": dict(D=3, W=96, input_ch=39, input_ch_views=0, output_ch=4, skips=[], use_viewdirs=False),
+}
+G11_DNERF = dict(D=4, W=64, input_ch=63, input_ch_views=27, input_ch_time=21, output_ch=5, skips=[1], use_viewdirs=True)
+
+
+def g11_weights(name):
+    kw = G11_NETS[name]
+    return generic_state_dict(1100 + sorted(G11_NETS).index(name), alpha_bias=-0.5, **kw)
+
+
+def g11_dnerf_weights():
+    kw = dict(G11_DNERF)
+    ct = kw.pop("input_ch_time")
+    sd = generic_state_dict(1150, alpha_bias=-0.5, prefix="_occ.", **kw)
+    rng = np.random.default_rng(1151)
+    W, D, skips, cin = kw["W"], kw["D"], kw["skips"], kw["input_ch"]
+    ins = [cin + ct] + [W + cin if i in skips else W for i in range(D - 1)]
+    for i, k in enumerate(ins):
+        sd[f"_time.{i}.weight"] = (rng.standard_normal((W, k)) * np.sqrt(2.0 / k)).astype(np.float32)
+        sd[f"_time.{i}.bias"] = (rng.standard_normal(W) * 0.05).astype(np.float32)
+    sd["_time_out.weight"] = (rng.standard_normal((3, W)) * np.sqrt(2.0 / W) * 0.05).astype(np.float32)
+    sd["_time_out.bias"] = (rng.standard_normal(3) * 0.01).astype(np.float32)
+    return sd
+
+
+def g11_inputs(n=300):
+    rng = np.random.default_rng(111)
+    pts = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    return dict(pts=pts, dirs=dirs.astype(np.float32), rays=g7_inputs(n=64, seed=111))

@@ -174,7 +174,7 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
         wd, wa = T(rng.standard_normal(n).astype(np.float32)).to(dev), T(rng.standard_normal(n).astype(np.float32)).to(dev)
 
         # the backward runs per chunk of rays (render.TRAIN_BWD_CHUNK_ROWS): force several ragged chunks here
-        monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", 2048 if n != 48 else 196608)
+        monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", 2048 if n != 48 else 393216)
 
         def run(op_path):
             if op_path:

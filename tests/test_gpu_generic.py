@@ -1,0 +1,158 @@
+"""Shapes the fused kernels are not built for run layer by layer on the generic fp32-MFMA GEMM kernels
+(csrc/generic_kernels.hip, swnerf/generic.py): `use_viewdirs=False` - the reference's argparse default, utils.py:26-29,
+model.py:59-60 -, other depths / widths / skip sets, DirectTemporalNeRF at D=4.  Against the reference's own outputs
+(G11, tests/golden/make_golden_generic.py) and, for gradients, torch autograd through the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, equal_nan=True, err_msg=what)
+
+
+def _net(dev, name):
+    import swnerf.model as model
+    m = model.vallina_NeRF(**cases.G11_NETS[name])
+    m.load_state_dict({k: T(v) for k, v in cases.g11_weights(name).items()}, strict=True)
+    return m.to(dev)
+
+
+def _embedded(dev, kw, g):
+    import swnerf.embedder as embedder
+    L = (kw["input_ch"] // 3 - 1) // 2
+    x = embedder.get_embedder(L, 3, 0)[0](T(g["pts"]).to(dev))
+    if kw["input_ch_views"]:
+        x = torch.cat([x, embedder.get_embedder(4, 3, 0)[0](T(g["dirs"]).to(dev))], -1)
+    return x
+
+
+def test_linear_kernel_shapes(dev):
+    """swnerf_linear / swnerf_gemm_nn / swnerf_relu_mask on ragged shapes (M, N, K not multiples of the 64 x 64 x 32
+    tile; K = 63, 319; a strided input) against float64 matmuls."""
+    from swnerf import generic
+    rng = np.random.default_rng(31)
+    for M, K, N, relu in ((1, 63, 256, True), (300, 319, 256, True), (65, 90, 5, False), (1000, 256, 3, False), (129, 7, 130, True), (0, 8, 4, False)):
+        lin = torch.nn.Linear(K, N).to(dev)
+        x = T(rng.standard_normal((M, K + 3)).astype(np.float32)).to(dev)[:, 1:K + 1]        # a strided view
+        with torch.no_grad():
+            y = generic.linear(x, lin, relu=relu)
+        ref = x.double() @ lin.weight.double().T + lin.bias.double()
+        ref = ref.clamp_min(0) if relu else ref
+        assert y.shape == (M, N)
+        close(y, ref.float(), atol=2e-5, rtol=1e-5, what=f"linear M={M} K={K} N={N}")
+    # autograd of one layer: dX, dW, db vs torch
+    lin = torch.nn.Linear(90, 37).to(dev)
+    x = T(rng.standard_normal((211, 90)).astype(np.float32)).to(dev).requires_grad_(True)
+    G = T(rng.standard_normal((211, 37)).astype(np.float32)).to(dev)
+    (generic.linear(x, lin, relu=True) * G).sum().backward()
+    got = [x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = None
+    lin.zero_grad()
+    (torch.relu(torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())) * G.double()).sum().backward()
+    for a, b, w in zip(got, (x.grad, lin.weight.grad, lin.bias.grad), ("dX", "dW", "db")):
+        close(a, b.float(), atol=2e-5 * float(b.abs().max()), what=w)
+
+
+def test_generic_mlps_golden(dev, golden):
+    import swnerf.embedder as embedder, swnerf.model as model
+    ref, g = golden("g11_generic"), cases.g11_inputs()
+    for name, kw in cases.G11_NETS.items():
+        net = _net(dev, name).eval()
+        assert not net._is_fused_arch()
+        with torch.no_grad():
+            out = net(_embedded(dev, kw, g))
+        close(out, ref[f"mlp_{name}"], atol=5e-5, rtol=1e-4, what=f"vallina_NeRF {name}")
+        assert net(_embedded(dev, kw, g)[:0]).shape == (0, kw["output_ch"] if not kw["use_viewdirs"] else 4)
+    kw = dict(cases.G11_DNERF)
+    e10 = embedder.get_embedder(10, 3, 0)[0]
+    dn = model.NeRF.get_by_name("direct_temporal", embed_fn=e10, zero_canonical=True, **kw)
+    dn.load_state_dict({k: T(v) for k, v in cases.g11_dnerf_weights().items()}, strict=True)
+    dn = dn.to(dev).eval()
+    x = _embedded(dev, kw, g)
+    et = embedder.get_embedder(10, 1, 0)[0]
+    for tv in (0.0, 0.5):
+        te = et(torch.full((x.shape[0], 1), tv, device=dev))
+        with torch.no_grad():
+            out, dx = dn(x, [te, te])
+        close(dx, ref[f"dnerf_dx_t{int(tv*10)}"], atol=2e-6, what=f"generic dnerf dx t={tv}")
+        close(out, ref[f"dnerf_out_t{int(tv*10)}"], atol=2e-3 if tv else 1e-4, rtol=1e-3, what=f"generic dnerf out t={tv}")   # gamma(x+dx): 2^9 band
+
+
+def test_render_without_viewdirs_golden(dev, golden):
+    """render() / render_rays with use_viewdirs=False (nerf/run.py:137-158 builds an 8-column ray batch; model.py:59-60):
+    the reference's own end-to-end outputs, and the dict keys / shapes of the drop-in."""
+    import swnerf.embedder as embedder, swnerf.render as render
+    ref, g = golden("g11_generic"), cases.g11_inputs()
+    net = _net(dev, "novd").eval()
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn = None
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    r = g["rays"]
+    K, _ = cases.synth.lego_camera(400, 400)
+    with torch.no_grad():
+        rgb, disp, acc, extras = render.render(400, 400, K, rays=(T(r["rays_o"]).to(dev), T(r["rays_d"]).to(dev)), ndc=False, near=2., far=6.,
+                                               use_viewdirs=False, network_fn=net, network_query_fn=q, N_samples=32, N_importance=32,
+                                               network_fine=None, white_bkgd=True, perturb=0., raw_noise_std=0.)
+    assert sorted(extras.keys()) == ["acc0", "disp0", "rgb0", "z_std"] and rgb.shape == (64, 3)
+    close(extras["rgb0"], ref["rr_rgb0"], atol=2e-5, what="rgb0 (no resampling in front)")
+    close(extras["acc0"], ref["rr_acc0"], atol=2e-5, what="acc0")
+    d = (rgb.cpu() - T(ref["rr_rgb_map"])).abs()
+    assert float((d <= 2e-4).float().mean()) >= 0.9 and float(d.max()) <= 2e-2, f"rgb_map: within 2e-4 {float((d <= 2e-4).float().mean()):.3f}, max {float(d.max()):.2e}"
+    close(extras["z_std"], ref["rr_z_std"], atol=2e-3, what="z_std")
+
+
+def test_generic_training_matches_autograd(dev):
+    """loss.backward() through the generic path: every parameter gradient of a use_viewdirs=False net and of the D=4
+    DirectTemporalNeRF (incl. the gradient through gamma(x + dx)) vs torch autograd through the CPU oracle."""
+    import swnerf.embedder as embedder, swnerf.model as model
+    g = cases.g11_inputs()
+    rng = np.random.default_rng(12)
+    with torch.enable_grad():
+        for name in ("novd", "small"):
+            kw = cases.G11_NETS[name]
+            net = _net(dev, name).train()
+            x = _embedded(dev, kw, g)
+            G = T(rng.standard_normal((x.shape[0], 5 if name == "novd" else 4)).astype(np.float32))
+            (net(x) * G.to(dev)).sum().backward()
+            sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(cases.g11_weights(name)).items()}
+            (O.generic_mlp(sd, x.cpu(), kw["D"], kw["skips"], kw["input_ch"], kw["input_ch_views"], kw["use_viewdirs"]) * G).sum().backward()
+            for k, p in net.named_parameters():
+                if sd[k].grad is None:                         # views_linears of a use_viewdirs=False net: unused (model.py:59-60)
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0
+                    continue
+                rg = sd[k].grad
+                assert float((p.grad.cpu() - rg).abs().max()) <= 3e-4 * max(float(rg.abs().max()), 1e-12), f"{name} {k}"
+        kw = dict(cases.G11_DNERF)
+        e10 = embedder.get_embedder(10, 3, 0)[0]
+        dn = model.NeRF.get_by_name("direct_temporal", embed_fn=e10, zero_canonical=True, **kw)
+        dn.load_state_dict({k: T(v) for k, v in cases.g11_dnerf_weights().items()}, strict=True)
+        dn = dn.to(dev).train()
+        x = _embedded(dev, kw, g)
+        te = embedder.get_embedder(10, 1, 0)[0](torch.full((x.shape[0], 1), 0.5, device=dev))
+        G, Gdx = T(rng.standard_normal((x.shape[0], 4)).astype(np.float32)), T(rng.standard_normal((x.shape[0], 3)).astype(np.float32))
+        out, dx = dn(x, [te, te])
+        ((out * G.to(dev)).sum() + (dx * Gdx.to(dev)).sum()).backward()
+        sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(cases.g11_dnerf_weights()).items()}
+        o_ref, dx_ref = O.generic_dnerf_mlp(sd, x.cpu(), te.cpu(), kw["D"], kw["skips"], kw["input_ch"], kw["input_ch_views"], True)
+        ((o_ref * G).sum() + (dx_ref * Gdx).sum()).backward()
+        for k, p in dn.named_parameters():
+            rg = sd[k].grad
+            # the gradient through gamma(x+dx) carries the 2^9 band: conditioning, not arithmetic
+            assert float((p.grad.cpu() - rg).abs().max()) <= 2e-3 * max(float(rg.abs().max()), 1e-12), f"dnerf {k}"

@@ -774,9 +774,10 @@ def test_errors_are_loud(sw, dev, nets):
     with pytest.raises(NotImplementedError):
         sw.embedder.Embedder(include_input=False, input_dims=3, max_freq_log2=9, num_freqs=10, log_sampling=True,
                              periodic_fns=[torch.sin, torch.cos])
-    bad = sw.model.vallina_NeRF(D=4, W=128, input_ch=63, input_ch_views=27, skips=[2], use_viewdirs=True).to(dev)
+    other = sw.model.vallina_NeRF(D=4, W=128, input_ch=63, input_ch_views=27, skips=[2], use_viewdirs=True).to(dev)
+    assert other(torch.zeros(4, 90, device=dev)).shape == (4, 4)        # not an error: the generic layer-by-layer path (test_gpu_generic.py)
     with pytest.raises(NotImplementedError):
-        bad(torch.zeros(4, 90, device=dev))
+        other.packed()                                               # ... but no packed stream for the fused kernels
     from swnerf import _lib
     a = _lib.PassArgs()
     rc = _lib.lib().swnerf_render_pass(a, None)

@@ -174,3 +174,36 @@ def test_g10_mesh_grid_query(golden):
     close(col.reshape(R, R, R, 3), ref["color"], atol=2e-6, rtol=1e-5)
     one = O.query_points(sd_f, pts[:40], torch.tensor(np.tile(vd[3][None], (40, 1)), dtype=torch.float32))
     close(one, ref["per_point_raw"], atol=2e-6, rtol=1e-5)
+
+
+def test_g11_generic_shapes(golden):
+    """The oracle's any-shape restatements (use_viewdirs=False, other D / W / skips, D-NeRF at D=4) against the
+    reference's outputs (tests/golden/make_golden_generic.py)."""
+    ref = golden("g11_generic")
+    g = cases.g11_inputs()
+    assert int(ref["checksum"][0]) == int(cases.checksum(g["pts"], g["dirs"], g["rays"]["rays_o"], g["rays"]["rays_d"])[0])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for name, kw in cases.G11_NETS.items():
+        sd = O.to_torch_sd(cases.g11_weights(name))
+        L = (kw["input_ch"] // 3 - 1) // 2
+        x = O.embed(T(g["pts"]), L)
+        if kw["input_ch_views"]:
+            x = torch.cat([x, O.embed(T(g["dirs"]), 4)], -1)
+        out = O.generic_mlp(sd, x, kw["D"], kw["skips"], kw["input_ch"], kw["input_ch_views"], kw["use_viewdirs"])
+        np.testing.assert_allclose(out.numpy(), ref[f"mlp_{name}"], atol=2e-5, rtol=1e-5)
+    kw = cases.G11_DNERF
+    sd = O.to_torch_sd(cases.g11_dnerf_weights())
+    x = torch.cat([O.embed(T(g["pts"]), 10), O.embed(T(g["dirs"]), 4)], -1)
+    for tv in (0.0, 0.5):
+        te = O.embed(torch.full((x.shape[0], 1), tv), 10)
+        out, dx = O.generic_dnerf_mlp(sd, x, te, kw["D"], kw["skips"], kw["input_ch"], kw["input_ch_views"], kw["use_viewdirs"])
+        np.testing.assert_allclose(dx.numpy(), ref[f"dnerf_dx_t{int(tv*10)}"], atol=1e-6)
+        np.testing.assert_allclose(out.numpy(), ref[f"dnerf_out_t{int(tv*10)}"], atol=2e-4, rtol=1e-4)
+    kwn = cases.G11_NETS["novd"]
+    sdn = O.to_torch_sd(cases.g11_weights("novd"))
+    r = g["rays"]
+    o_, d_ = T(r["rays_o"]), T(r["rays_d"])
+    rb = torch.cat([o_, d_, 2. * torch.ones_like(d_[:, :1]), 6. * torch.ones_like(d_[:, :1])], -1)
+    ret = O.render_rays_generic(rb, lambda e: O.generic_mlp(sdn, e, kwn["D"], kwn["skips"], kwn["input_ch"], 0, False), 32, 32, white_bkgd=True)
+    for k in ("rgb0", "acc0", "rgb_map", "acc_map", "z_std"):
+        np.testing.assert_allclose(ret[k].numpy(), ref[f"rr_{k}"], atol=2e-5 if k.endswith("0") else 5e-4, err_msg=k)
