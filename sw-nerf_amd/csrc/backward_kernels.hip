@@ -130,12 +130,11 @@ struct GemmTN { const float* A; int lda; int No; const float* B; int ldb; int Ni
 #define GT_SLAB 32                     // rows per LDS slab = 16 k-steps
 // One workgroup (8 waves) owns a 128(o) x 256(i) block of C for its row slice; wave w owns the 32 x 128 strip
 // o in [32(w&3), +32), i in [128(w>>2), +128) as 4 accumulator tiles.  A (32 x 128) and B (32 x 256) slabs are
-// staged through 48 KB of LDS, SINGLE buffered: load -> barrier -> MFMA -> barrier.  Overlap of memory and
-// matrix work comes from 2-3 co-resident workgroups per CU (one loads while another computes), not from a
-// register prefetch: hipcc spills a prefetched slab to scratch at this register budget (load -> vmcnt(0) ->
-// scratch_store), and scratch traffic shares vmcnt with everything else.
-// VA / VB: that operand is 16-byte aligned with a column count that is a multiple of 4 -> float4 loads; otherwise
-// 4-byte loads with column masks.
+// staged through 48 KB of LDS by LDS-DMA, SINGLE buffered: DMA -> vmcnt(0) -> barrier -> MFMA -> barrier.  Overlap of
+// memory and matrix work comes from 2 co-resident workgroups per CU (one loads while another computes); the
+// 128-register budget that allows them is why nothing may be staged through registers (round 1 did, and spilled).
+// VA / VB: that operand is 16-byte aligned with a column count that is a multiple of 4 -> 16-byte DMAs; otherwise
+// 4-byte DMAs.
 template <bool VA, bool VB>
 __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
     __shared__ __attribute__((aligned(16))) float As[GT_SLAB][128];
@@ -157,75 +156,57 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
     float bsum = 0.f;
     const float* Ab = P.A + m0 * P.lda + obase;
     const float* Bb = P.B + m0 * P.ldb + i0;
+    const unsigned as_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&As[0][0]);
+    const unsigned bs_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&Bs[0][0]);
     for (int mrel = 0; mrel < mlen; mrel += GT_SLAB) {
-        // ---- stage the slab.  All loads are UNCONDITIONAL (clamped addresses) and issued back to back; rows /
-        // columns outside the problem are zeroed at the LDS write.  (A load under `if` becomes a branch with its
-        // LDS write right behind it: one serialised memory round trip per load - measured 6 us per slab.)
+        // ---- stage the slab by LDS-DMA: no staging registers at all (with register staging this kernel spilled
+        // 56-176 B/lane at its 128-register budget, and scratch traffic shares vmcnt with everything else).  An operand
+        // whose base, leading dimension and column count allow 16-byte accesses (VA / VB) moves 1 KiB per instruction
+        // (`global_load_lds_dwordx4`), any other (x[:, :63] with ld 90, d_out[:, 3] with ld 4) 256 B per instruction
+        // (`global_load_lds_dword`, one float per lane).  Nothing can be zero-filled on the way, so rows past the slice
+        // and columns past the operand are CLAMPED to valid addresses instead: a clamped column only feeds C entries
+        // that are never written, a clamped row is masked on the A side in the MFMA loop below.
         const unsigned rlast = (unsigned)(mlen - 1 - mrel);
-        // per operand: 16-byte loads when its base, leading dimension and column count allow (VA / VB), else 4-byte
-        // loads with column masks (x[:, :63] with ld 90, d_out[:, 3] with ld 4).  Mixed cases matter: the narrow GEMMs
-        // pair one such operand with a 256-wide window of grad/act, which is most of their traffic.
-        f32x4 va4[VA ? 2 : 1], vb4[VB ? 4 : 1];
-        float va1[VA ? 1 : 8], vb1[VB ? 1 : 16];
         if (VA) {
+            const unsigned col = (obase + 4 * i < P.No) ? 4u * i : 0u;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {            // A: 32 x 128 floats = 1024 float4
-                const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
-                va4[k] = *reinterpret_cast<const f32x4*>(Ab + (mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c4 < P.No) ? c4 : 0));
+            for (int q = 0; q < 2; ++q) {            // A: 32 rows x 512 B = 16 DMAs of two rows, 2 per wave
+                const int r0 = 2 * (wv * 2 + q);
+                ws_dma(reinterpret_cast<const char*>(Ab), ((mrel + min((unsigned)(r0 + hp), rlast)) * (unsigned)P.lda + col) * 4u,
+                       as_addr + (unsigned)r0 * 512u);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int f = t + 512 * k, row = f >> 7, c = f & 127;
-                va1[k] = Ab[(mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c < P.No) ? c : 0)];
+            for (int k = 0; k < 8; ++k) {            // 4096 floats = 64 DMAs of 64 floats (half a row), 8 per wave
+                const int f0 = 512 * k + 64 * wv, row = f0 >> 7, c = (f0 & 127) + lane;
+                lds_dma_dword(reinterpret_cast<const char*>(Ab),
+                              ((mrel + min((unsigned)row, rlast)) * (unsigned)P.lda + ((obase + c < P.No) ? c : 0)) * 4u, as_addr + (unsigned)f0 * 4u);
             }
         }
         if (VB) {
+            const unsigned col = (i0 + 4 * lane < P.Ni) ? 4u * lane : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {            // B: 32 x 256 floats = 2048 float4
-                const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
-                vb4[k] = *reinterpret_cast<const f32x4*>(Bb + (mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c4 < P.Ni) ? c4 : 0));
+            for (int q = 0; q < 4; ++q) {            // B: 32 rows x 1 KiB = 32 DMAs, 4 per wave
+                const int row = wv * 4 + q;
+                ws_dma(reinterpret_cast<const char*>(Bb), ((mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + col) * 4u,
+                       bs_addr + (unsigned)row * 1024u);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int f = t + 512 * k, row = f >> 8, c = f & 255;
-                vb1[k] = Bb[(mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c < P.Ni) ? c : 0)];
+            for (int k = 0; k < 16; ++k) {           // 8192 floats = 128 DMAs of 64 floats (a quarter row), 16 per wave
+                const int f0 = 512 * k + 64 * wv, row = f0 >> 8, c = (f0 & 255) + lane;
+                lds_dma_dword(reinterpret_cast<const char*>(Bb),
+                              ((mrel + min((unsigned)row, rlast)) * (unsigned)P.ldb + ((i0 + c < P.Ni) ? c : 0)) * 4u, bs_addr + (unsigned)f0 * 4u);
             }
         }
-        const f32x4 z = {};
-        if (VA) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int f = t + 512 * k, row = f >> 5, c4 = 4 * (f & 31);
-                *reinterpret_cast<f32x4*>(&As[row][c4]) = ((unsigned)row <= rlast && obase + c4 < P.No) ? va4[k] : z;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int f = t + 512 * k, row = f >> 7, c = f & 127;
-                As[row][c] = ((unsigned)row <= rlast && obase + c < P.No) ? va1[k] : 0.f;
-            }
-        }
-        if (VB) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = t + 512 * k, row = f >> 6, c4 = 4 * (f & 63);
-                *reinterpret_cast<f32x4*>(&Bs[row][c4]) = ((unsigned)row <= rlast && i0 + c4 < P.Ni) ? vb4[k] : z;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int f = t + 512 * k, row = f >> 8, c = f & 255;
-                Bs[row][c] = ((unsigned)row <= rlast && i0 + c < P.Ni) ? vb1[k] : 0.f;
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (strip) {
             if (nb == 4) {                           // full-width strip: batched LDS reads, branch-free MFMA groups
-#pragma unroll 4
+#pragma unroll 2
                 for (int s = 0; s < GT_SLAB / 2; ++s) {
-                    const float a = As[2 * s + hp][o0 + i];
+                    float a = As[2 * s + hp][o0 + i];
+                    a = ((unsigned)(2 * s + hp) <= rlast) ? a : 0.f;              // rows past the slice (clamped copies)
                     float bv[4];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) bv[b] = Bs[2 * s + hp][ih + 32 * b + i];
@@ -236,7 +217,8 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
             } else {
 #pragma unroll 2
                 for (int s = 0; s < GT_SLAB / 2; ++s) {
-                    const float a = As[2 * s + hp][o0 + i];
+                    float a = As[2 * s + hp][o0 + i];
+                    a = ((unsigned)(2 * s + hp) <= rlast) ? a : 0.f;
                     bsum += a;
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -247,20 +229,24 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
         __syncthreads();
     }
     if (!strip) return;
-    // C/D map: register r of lane (j = i, h = hp) is row obase + o0 + frow(r,h), column i0 + ih + 32b + j
+    // C/D map: register r of lane (j = i, h = hp) is row obase + o0 + frow(r,h), column i0 + ih + 32b + j.
+    // The lane index is taken afresh from mbcnt here: carried over from the prologue it stays live across the slab
+    // loop, and at this kernel's 128-register budget that was the one value hipcc still spilled.
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int ie = lane_e & 31, he = lane_e >> 5;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         if (b >= nb) continue;
-        const int col = i0 + ih + 32 * b + i;
+        const int col = i0 + ih + 32 * b + ie;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = obase + o0 + sw_frow(r, hp);
+            const int o = obase + o0 + sw_frow(r, he);
             if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
     if (P.bias && (blockIdx.y >> 1) == 0 && ih == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (hp == 0 && (obase + o0 + i) < P.No) atomicAdd(P.bias + obase + o0 + i, bsum);
+        if (he == 0 && (obase + o0 + ie) < P.No) atomicAdd(P.bias + obase + o0 + ie, bsum);
     }
 }
 
@@ -516,7 +502,7 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
     rows = (rows + GT_SLAB - 1) / GT_SLAB * GT_SLAB;
     P.rows_per_wg = rows;
     nwg = (M + rows - 1) / rows;
-    if (rows * (int64_t)(lda > ldb ? lda : ldb) >= (1LL << 31)) return sw_fail(SWNERF_E_UNSUPP, "gemm_tn: row slice too large for 32-bit offsets");
+    if (rows * (int64_t)(lda > ldb ? lda : ldb) >= (1LL << 30)) return sw_fail(SWNERF_E_UNSUPP, "gemm_tn: row slice too large for 32-bit byte offsets");
     const dim3 grid((unsigned)nwg, (unsigned)(((Ni + 255) / 256) * (No > 128 ? 2 : 1))), block(512);
     const bool va = (lda % 4 == 0) && (No % 4 == 0) && ((uintptr_t)A % 16 == 0);
     const bool vb = (ldb % 4 == 0) && (Ni % 4 == 0) && ((uintptr_t)B % 16 == 0);

@@ -76,7 +76,31 @@ def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col
                                       off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3), st), "gemm_tn_fused")
 
 
-def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
+def _rgb4_buffers(device):
+    """Zeroed 4-row accumulators (weight [4,128], bias [4]) for rgb_linear's gradient, see _rgb_weight_grad."""
+    return (torch.zeros((4, 128), dtype=torch.float32, device=device), torch.zeros((4,), dtype=torch.float32, device=device))
+
+
+def _rgb_weight_grad(L, st, M, d_out, act, g, rgb4):
+    """rgb_linear: dW [3,128] += d rgb^T . hv.  d_out is [M,4] = [d rgb(3), d sigma]; taking all FOUR columns as output
+    rows keeps the operand 16-byte aligned with a column count that is a multiple of 4, i.e. on the LDS-DMA staged
+    variant of the GEMM kernel (the 3-column form falls to 4-byte loads): it accumulates into the 4-row buffers
+    `rgb4`, whose first three rows the caller hands out as the gradient (_rgb4_finish); the 4th row is dropped."""
+    if rgb4 is None or d_out.stride(0) != 4 or d_out.data_ptr() % 16:
+        _gemm_tn(L, st, M, d_out, 0, 3, act, SW_ACT_HV, 128, g[22], 0, g[23])
+    else:
+        _gemm_tn(L, st, M, d_out, 0, 4, act, SW_ACT_HV, 128, rgb4[0], 0, rgb4[1])
+
+
+def _rgb4_finish(g, rgb4):
+    g[22] = g[22] + rgb4[0][:3]
+    g[23] = g[23] + rgb4[1][:3]
+
+
+SW_ACT_HV = 2304          # csrc/swnerf_common.h: column of the view hidden layer in the act / grad rows
+
+
+def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g, rgb4=None):
     """dW / db of the 12 Linear layers of the canonical net (g: zeroed fp32 tensors in _CANON_ORDER) from the
     dX chain's `grad`, the saved `act`, the embedded inputs x = [gamma(x) | gamma(d)] and d raw."""
     mm = lambda A, a_col, No, B, b_col, Ni, wi, c_col, with_bias: _gemm_tn(
@@ -90,7 +114,7 @@ def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g):
     mm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
     # feature_linear, and alpha_linear riding on its pass over h7
     _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
-    mm(d_out, 0, 3, act, 2304, 128, 22, 0, True)                               # rgb_linear
+    _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
 
 
 def _slot_buffers(device):
@@ -99,7 +123,7 @@ def _slot_buffers(device):
     return slots[:16384].view(256, 64), slots[16384:32768].view(256, 64), slots[32768:].view(128, 32)
 
 
-def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slot_bufs):
+def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slot_bufs, rgb4=None):
     """The same 12 weight gradients for the FUSED training pass (accumulating: call once per row chunk): the
     encodings come as xs [M, 96] in operand slot order (64 slots gamma(x), 32 slots gamma(d); csrc/swnerf_common.h
     sw_xs_col), so the three GEMMs against them accumulate slot-ordered columns into `slot_bufs`, which
@@ -114,7 +138,7 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slo
     mm(grad, 2304, 128, act, 2048, 256, g[16], 0, g[17])                       # views_linears.0 = [feature | dirs]
     mm(grad, 2304, 128, xs, 64, 32, cvs, 0, None)
     _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
-    mm(d_out, 0, 3, act, 2304, 128, g[22], 0, g[23])                           # rgb_linear
+    _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
 
 
 def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g):
@@ -158,7 +182,9 @@ class _MlpTrain(torch.autograd.Function):
         _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(bits), _lib.ptr(d_out), M, _lib.ptr(grad), st),
                    "mlp_backward_dx")
         g = _zero_grads(params)                                               # order: _CANON_ORDER
-        _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g)
+        rgb4 = _rgb4_buffers(x.device)
+        _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g, rgb4)
+        _rgb4_finish(g, rgb4)
         return (None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
@@ -214,7 +240,9 @@ class _DnerfTrain(torch.autograd.Function):
         _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(bits_c), _lib.ptr(d_out),
                                                 _lib.ptr(pts2), M, Lp, _lib.ptr(grad_c), _lib.ptr(d_pts), st), "mlp_backward_dx_pts")
         g = _zero_grads(params)
-        _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g[:24])
+        rgb4 = _rgb4_buffers(x.device)
+        _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g, rgb4)      # (fills g[0..23])
+        _rgb4_finish(g, rgb4)
         g_dx = d_pts if d_dx is None else (d_pts + d_dx.float()).contiguous()
         grad_d = torch.empty_like(act_d)
         _lib.check(L.swnerf_deform_backward_dx(_lib.ptr(module.packed_bwd(_lib.BWD_DEFORM)), _lib.ptr(bits_d), _lib.ptr(g_dx), M,

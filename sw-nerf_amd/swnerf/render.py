@@ -199,7 +199,7 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs):
-        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads
+        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -209,7 +209,7 @@ class _FusedPassTrain(torch.autograd.Function):
         c = lambda g: None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_acc = c(g_rgb), c(g_disp), c(g_acc)
         g = _zero_grads(params)
-        slot_bufs = _slot_buffers(rb.device)
+        slot_bufs, rgb4 = _slot_buffers(rb.device), _rgb4_buffers(rb.device)
         # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
         # it run per CHUNK of rays, so only one chunk of it is ever alive (GEMMs accumulate: C += A^T.B).  A chunk is
         # 393 216 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
@@ -229,8 +229,9 @@ class _FusedPassTrain(torch.autograd.Function):
                 _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(grad), _lib.ptr(d_raw), st),
                 "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs)
+            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
         _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
+        _rgb4_finish(g, rgb4)
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
