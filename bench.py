@@ -163,10 +163,15 @@ def extra_configs(dev):
     rows = []
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False):
+    from oracle import nerf_oracle as O
+
+    def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False, ref=None):
+        """ref: None, or callable(first 256 rows of fn()'s rgb on the GPU) -> the CPU oracle's rgb for the same rays
+        (the checker, outside the timed region): PSNR of the HIP render against it goes into the row."""
         ctx = torch.enable_grad() if grad else torch.no_grad()
         with ctx:
-            fn(); fn()
+            out = fn()
+            fn()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -176,6 +181,12 @@ def extra_configs(dev):
         tf = n_rays * flop_per_ray / dt / 1e12
         rows.append({"name": name, "ms": dt * 1e3, "rays_per_s": n_rays / dt, "algorithmic_tflops": tf,
                      "frac": tf / PEAK_FP32_MFMA_TFLOPS, "reps": reps})
+        if ref is not None:
+            with torch.no_grad():
+                want = ref()
+            got = (out[0] if isinstance(out, (list, tuple)) else out[:, :3]).reshape(-1, 3)[:want.shape[0]].cpu()
+            rows[-1]["psnr_vs_cpu_render_db"] = float(-10 * np.log10(max(float(((got - want) ** 2).mean()), 1e-20)))
+            rows[-1]["psnr_rays"] = int(want.shape[0])
 
     st = build_scene("C2", dev, 0)
     kw, K8, c2w8 = st["kw"], st["K"], st["c2w"]
@@ -183,21 +194,33 @@ def extra_configs(dev):
     o, d = synth.pick_rays(400, 400, K4, c2w4, 1024, 1)
     r1 = (T(o), T(d))
     kw1 = dict(kw, N_importance=0, network_fine=None)
-    timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50)
+    sd_c, sd_f = (O.to_torch_sd(sd_) for sd_ in st["sds_np"])
+    rb1 = O.make_ray_batch(torch.from_numpy(o), torch.from_numpy(d), 2., 6.)
+    timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50,
+           ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"])
     Kf, c2wf = synth.fern_camera()
     o, d = synth.pick_rays(378, 504, Kf, c2wf, N_RAND, 3)
     r3 = (T(o), T(d))
     kw3 = dict(kw, ndc=True, near=0., far=1., white_bkgd=False)
-    timeit("C3: fern-like NDC rays, 4096 x (64+128)", lambda: render.render(378, 504, Kf, rays=r3, **kw3), N_RAND, st["flop_per_ray"], 10)
+    rb3 = O.make_ray_batch(torch.from_numpy(o[:512]), torch.from_numpy(d[:512]), 0., 1., ndc=True, H=378, W=504, focal=float(Kf[0][0]))
+    timeit("C3: fern-like NDC rays, 4096 x (64+128)", lambda: render.render(378, 504, Kf, rays=r3, **kw3), N_RAND, st["flop_per_ray"], 10,
+           ref=lambda: O.render_rays(rb3, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=False)["rgb_map"])
     lo, hi = synth.shard_range(800 * 800, 8, 3)
     rr4 = parallel.frame_renderer(800, 800, K8, c2w8, kw, device=dev)
-    timeit("C4 shard: rank 3 of 8 of the 800x800 frame, 80 000 rays incl. get_rays", lambda: rr4(lo, hi - lo), hi - lo, st["flop_per_ray"], 3)
+    o8, d8 = O.get_rays(800, 800, K8, c2w8)
+    rb4 = O.make_ray_batch(o8.reshape(-1, 3)[lo:lo + 512], d8.reshape(-1, 3)[lo:lo + 512], 2., 6.)
+    timeit("C4 shard: rank 3 of 8 of the 800x800 frame, 80 000 rays incl. get_rays", lambda: rr4(lo, hi - lo), hi - lo, st["flop_per_ray"], 3,
+           ref=lambda: O.render_rays(rb4, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
     s5 = build_scene("C5", dev, 0)
     lo5, hi5 = synth.shard_range(400 * 400, 8, 3)
+    sd_d = O.to_torch_sd(s5["sds_np"][0])
+    o4, d4 = O.get_rays(400, 400, float(s5["K"][0][0]), s5["c2w"])
     for tv in (0.5, 0.0):
         rr5 = parallel.frame_renderer(400, 400, s5["K"], s5["c2w"], s5["kw"], frame_time=tv, device=dev)
+        rb5 = O.make_ray_batch(o4.reshape(-1, 3)[lo5:lo5 + 256], d4.reshape(-1, 3)[lo5:lo5 + 256], 2., 6., frame_time=tv)
         timeit(f"C5 shard: D-NeRF rank 3 of 8 of the 400x400 frame, 20 000 rays, t={tv}", lambda: rr5(lo5, hi5 - lo5), hi5 - lo5,
-               s5["flop_per_ray"] if tv else st["flop_per_ray"], 3)
+               s5["flop_per_ray"] if tv else st["flop_per_ray"], 3,
+               ref=lambda rb5=rb5: O.render_rays_dnerf(rb5, sd_d, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
     # training step of the reference (nerf/run.py:684-708): render -> img2mse -> backward -> Adam; 3x the forward FLOPs
     nets = [kw["network_fn"], kw["network_fine"]]
     for m in nets:
@@ -389,7 +412,8 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_extra:
         render.PASS_HOOK = None
         result["extra"] = {"note": "measured after and outside the headline's timed region, same process and GPU; wall clock per "
-                                   "call incl. Python; frac = algorithmic MLP FLOPs / time / 157.3 TFLOP/s",
+                                   "call incl. Python; frac = algorithmic MLP FLOPs / time / 157.3 TFLOP/s; psnr_vs_cpu_render_db = the "
+                                   "HIP render against the CPU oracle's render of the first psnr_rays rays of that config",
                            "configs": extra_configs(dev)}
     if rank == 0:
         print(json.dumps(result), flush=True)

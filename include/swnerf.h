@@ -167,6 +167,7 @@ int swnerf_gemm_tn_fused(const float* A, int lda, const float* B, int ldb, int64
 #define SWNERF_BWD_CANON 0
 #define SWNERF_BWD_CANON_INPUT_GRAD 1
 #define SWNERF_BWD_DEFORM 2
+#define SWNERF_BWD_DNERF_FUSED       3   /* CANON_INPUT_GRAD then DEFORM as ONE stream (params: the 42 DirectTemporalNeRF tensors) */
 size_t swnerf_packed_bwd_floats_kind(int bwd_kind);
 int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
                              float* packed_bwd, void* stream);
@@ -250,19 +251,37 @@ int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);
  * render_pass_backward: gradients of (rgb_map, disp_map, acc_map) -> d raw [rows,4] (padded rows; zeros past S) and
  * the gradient of every layer's pre-activation grad [rows, act floats] (as swnerf_mlp_backward_dx), one wavefront
  * per ray: compositing backward in the wave's LDS slice, then the dX chain tile by tile.  packed_bwd:
- * swnerf_pack_net_bwd_kind(SWNERF_BWD_CANON).  g_* may each be NULL.  z_vals [N,S]: the depths the forward used. */
+ * swnerf_pack_net_bwd_kind(SWNERF_BWD_CANON).  g_* may each be NULL; g_raw = upstream gradient of the returned raw
+ * (retraw=True: the reference's trainers ask for it, nerf/run.py:685) is added to d raw.  z_vals [N,S]: the depths the forward used. */
 int64_t swnerf_train_rows(int64_t n_rays, int n_samples);
 int swnerf_xs_floats_per_row(void);
 int swnerf_render_pass_train(const swnerf_pass_args* args /*HOST*/, float* act, float* bits, float* xs, void* stream);
 int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, const float* raw /*[N,S,4]*/,
                                 const float* z_vals /*[N,S]*/, const float* ray_batch, int cols, const float* noise,
                                 int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb /*[N,3]*/,
-                                const float* g_disp /*[N]*/, const float* g_acc /*[N]*/, float* grad, float* d_raw,
-                                void* stream);
+                                const float* g_disp /*[N]*/, const float* g_acc /*[N]*/, const float* g_raw /*[N,S,4] or NULL*/,
+                                float* grad, float* d_raw, void* stream);
+/* The same pair for DirectTemporalNeRF at t != 0 (model.py:128-151; the loss of d_nerf/run_dnerf.py:690-725 puts
+ * gradients on the image AND on position_delta).  No resampling in the training pass (n_importance must be 0: the
+ * one-model configuration's coarse pass is a no_grad inference pass, run_dnerf.py:417-421).  args->dx (position_delta
+ * [N,S,3]) and args->raw are required outputs.  *_d: the deformation net's buffers, sized like the canonical ones
+ * (act_d uses the first 2048 columns; xs_d = gamma(x) 64 slots + gamma(t) 32 slots).
+ * backward: packed_bwd_fused = swnerf_pack_net_bwd_kind(SWNERF_BWD_DNERF_FUSED); dx = the forward's position_delta;
+ * g_position_delta [N,S,3] its upstream gradient or NULL; outputs grad / grad_d [rows, act floats], d_raw [rows,4],
+ * g_dx [rows,4] = d dx (4th column 0) - the A operand of the `_time_out` weight-gradient GEMM. */
+int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args /*HOST*/, float* act, float* bits, float* xs,
+                                   float* act_d, float* bits_d, float* xs_d, void* stream);
+int swnerf_render_pass_backward_dnerf(const float* packed_bwd_fused, const float* bits, const float* bits_d, const float* raw,
+                                      const float* z_vals, const float* ray_batch, int cols, const float* noise, const float* dx,
+                                      const float* g_position_delta, int64_t n_rays, int n_samples, int white_bkgd, int L_pos,
+                                      const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_raw,
+                                      float* grad, float* grad_d, float* d_raw, float* g_dx, void* stream);
 /* Cs [rows_w, nslots] holds weight-gradient columns in slot order (a TN GEMM against xs[:, slot0 : slot0+nslots]):
  * W[o][col0 + column(slot0 + f)] = Cs[o][f] for every real slot f; pad slots are dropped. */
 int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nslots, int L_pos, int L_dir,
                        float* W, int ldw, int col0, void* stream);
+/* ... for xs_d: slots 64..95 hold gamma(t) (L_time bands) instead of gamma(d) */
+int swnerf_unslot_grad_time(const float* Cs, int ld_s, int rows_w, int nslots, int L_time, float* W, int ldw, int col0, void* stream);
 
 /* ---- any-shape MLP layers (model.py:10-62, 93-151, 227-296 at shapes the fused kernels are not built for:
  * use_viewdirs=False - the reference's argparse default, utils.py:26-29 / model.py:59-60 -, other D / W / skips) -------

@@ -538,3 +538,21 @@ extern "C" int swnerf_unslot_grad(const float* Cs, int ld_s, int rows, int slot0
                        nslots, L_pos, L_dir, W, ldw, col0);
     return sw_check(hipGetLastError(), "unslot_grad launch");
 }
+
+// xs_d of the fused D-NeRF training pass carries gamma(t) in its third k-tile: slot f (0..31) -> sw_time_col
+__global__ void __launch_bounds__(256) unslot_time_kernel(const float* Cs, int ld_s, int rows, int nslots, int Lt, float* W, int ldw, int col0) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nslots) return;
+    const int o = idx / nslots, f = idx - o * nslots;
+    const int g = (f >> 3) & 3, h = (f >> 2) & 1, e = f & 3;
+    const int col = sw_time_col(4 * g + e, h, Lt);
+    if (col >= 0) W[(size_t)o * ldw + col0 + col] = Cs[(size_t)o * ld_s + f];
+}
+
+extern "C" int swnerf_unslot_grad_time(const float* Cs, int ld_s, int rows, int nslots, int L_time, float* W, int ldw, int col0, void* stream) {
+    if (!Cs || !W || rows < 1 || nslots < 1 || nslots > 32 || ld_s < nslots || L_time < 0 || L_time > 10)
+        return sw_fail(SWNERF_E_ARG, "unslot_grad_time: bad arguments (rows=%d nslots=%d ld_s=%d L_time=%d)", rows, nslots, ld_s, L_time);
+    const int total = rows * nslots;
+    hipLaunchKernelGGL(unslot_time_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Cs, ld_s, rows, nslots, L_time, W, ldw, col0);
+    return sw_check(hipGetLastError(), "unslot_grad_time launch");
+}

@@ -364,7 +364,8 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
                 f32x16 k3[3];
                 k3[0] = emb[0]; k3[1] = emb[1];
                 pe_time(t, h, k3[2]);
-                seg_mfma<8, 3, SEG_BIAS>(out, k3, ws);
+                if (XS) seg_mfma<8, 3, SEG_BIAS, 3>(out, k3, ws, 1.f, SideStore{xs_row, nullptr, mbits});   // gamma(x), gamma(t) -> xs
+                else seg_mfma<8, 3, SEG_BIAS>(out, k3, ws);
             } else if (XS) {
                 seg_mfma<8, 2, SEG_BIAS, 2>(out, emb, ws, 1.f, SideStore{xs_row, nullptr, mbits});
             } else {

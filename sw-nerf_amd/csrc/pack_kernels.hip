@@ -206,16 +206,17 @@ extern "C" size_t swnerf_packed_bwd_floats_kind(int bwd_kind) {
         case SWNERF_BWD_CANON: return (size_t)SW_BWD_FLOATS;
         case SWNERF_BWD_CANON_INPUT_GRAD: return (size_t)SW_BWD_IG_FLOATS;
         case SWNERF_BWD_DEFORM: return (size_t)SW_DBWD_FLOATS;
+        case SWNERF_BWD_DNERF_FUSED: return (size_t)SW_BWD_DN_FLOATS;
     }
     return 0;
 }
 
 extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
     if (!params || !packed_bwd) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: NULL pointer");
-    if (bwd_kind != SWNERF_BWD_CANON && bwd_kind != SWNERF_BWD_CANON_INPUT_GRAD && bwd_kind != SWNERF_BWD_DEFORM)
+    if (bwd_kind != SWNERF_BWD_CANON && bwd_kind != SWNERF_BWD_CANON_INPUT_GRAD && bwd_kind != SWNERF_BWD_DEFORM && bwd_kind != SWNERF_BWD_DNERF_FUSED)
         return sw_fail(SWNERF_E_ARG, "pack_net_bwd: unknown stream kind %d", bwd_kind);
     if (L_pos < 0 || L_pos > 10 || L_dir < 0 || L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "pack_net_bwd: embedder bands (%d,%d) exceed (10,4)", L_pos, L_dir);
-    const int np = bwd_kind == SWNERF_BWD_DEFORM ? 18 : 24;
+    const int np = bwd_kind == SWNERF_BWD_DEFORM ? 18 : (bwd_kind == SWNERF_BWD_DNERF_FUSED ? 42 : 24);
     for (int i = 0; i < np; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: params[%d] is NULL", i);
     const int Cpos = 3 * (1 + 2 * L_pos), Cdir = 3 * (1 + 2 * L_dir);
     hipStream_t st = (hipStream_t)stream;
@@ -233,8 +234,9 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
         pk.vecs(params[16], 3, 256);                                  // _time_out.weight rows, tile n: [h][r] = w[o][32n + frow(r,h)]
         return pk.rc;
     }
-    const bool ig = bwd_kind == SWNERF_BWD_CANON_INPUT_GRAD;
-    const size_t wfloats = ig ? SW_BWD_IG_W_FLOATS : SW_BWD_W_FLOATS;
+    const bool fused = bwd_kind == SWNERF_BWD_DNERF_FUSED;
+    const bool ig = bwd_kind == SWNERF_BWD_CANON_INPUT_GRAD || fused;
+    const size_t wfloats = fused ? SW_BWD_DN_W_FLOATS : (ig ? SW_BWD_IG_W_FLOATS : SW_BWD_W_FLOATS);
     Packer pk{st, packed_bwd, packed_bwd + wfloats, L_pos, L_dir, 0, 0};
     pk.segT(params[22], 3, 128, 0, 128, 4, 1);                       // rgb_linear.weight [3,128]^T
     pk.segT(params[16], 128, 256 + Cdir, 0, 256, 8, 4);              // views_linears.0.weight[:, :256]^T
@@ -244,9 +246,13 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
         pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
     }
     if (ig) pk.segT(params[0], 256, Cpos, 0, Cpos, 2, 8, 1);         // pts_linears.0.weight^T -> d gamma(x)
-    int rc = tail(pk, ig ? SW_BWD_IG_STEPS : SW_BWD_STEPS);
+    if (fused)                                                       // ... then the deformation net's chain in the same ring
+        for (int l = 7; l >= 1; --l)
+            pk.segT(params[24 + 2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
+    int rc = tail(pk, fused ? SW_BWD_DN_STEPS : (ig ? SW_BWD_IG_STEPS : SW_BWD_STEPS));
     if (rc) return rc;
     pk.vecs(params[20], 1, 256);                                     // alpha_linear.weight [1,256] as 8 bias-style tiles
+    if (fused) pk.vecs(params[40], 3, 256);                          // _time_out.weight rows as 3 x 8 tiles
     return pk.rc;
 }
 

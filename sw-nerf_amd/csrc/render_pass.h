@@ -28,6 +28,8 @@ struct PassDev {
     float* act;             // [rows, SW_ACT_LD]   post-ReLU activations (column map: swnerf_common.h)
     float* bits;            // [rows/32, SW_MASK_TILE_FLOATS]   ReLU bit masks
     float* xs;              // [rows, SW_XS_LD]    the encodings gamma(x), gamma(d) in B-operand SLOT order (sw_xs_col)
+    // TRAIN + DNERF: the same three for the deformation net (act_d uses the first 2048 columns; xs_d = gamma(x), gamma(t))
+    float* act_d; float* bits_d; float* xs_d;
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -82,16 +84,17 @@ __device__ __forceinline__ float z_sample(const swnerf_pass_args& a, int64_t ray
 }
 
 // ------------------------------------------------------------------------------------------
-// TRAIN: the static net only.  The LDS bias region then holds the canonical tiles alone (the deformation tiles' 11 KB
-// are what lets the 16-deep ring of the training translation unit and the resampling scratch fit into 160 KB).
-template <bool TRAIN> struct PassLds {
-    static constexpr int BIAS = TRAIN ? SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS : SW_LDS_BIAS_FLOATS;
+// TRAIN, static net: the LDS bias region holds the canonical tiles alone (the deformation tiles' 11 KB are what lets the
+// 16-deep ring of the training translation unit AND the resampling scratch fit into 160 KB).  TRAIN + DNERF keeps both
+// tile sets and has no resampling scratch (the D-NeRF training pass runs on given depths: the coarse pass of the
+// one-model configuration is a no_grad inference pass, d_nerf/run_dnerf.py:417-421).
+template <bool DNERF, bool TRAIN> struct PassLds {
+    static constexpr int BIAS = (TRAIN && !DNERF) ? SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS : SW_LDS_BIAS_FLOATS;
     static constexpr int FIXED = BIAS + 4 * SW_LDS_RING_FLOATS;
 };
 
 template <bool DNERF, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
-    static_assert(!(DNERF && TRAIN), "the fused training pass is built for the static net");
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const swnerf_pass_args& a = P.a;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -100,9 +103,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     bias_to_lds(lds_all, P.b0, P.nbias);         // the only block barrier; waves are independent after it
     if (ray >= a.n_rays) return;                 // wave-uniform
     const float* lds_bias = lds_all;
-    float* lds_ring = lds_all + PassLds<TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS;
+    float* lds_ring = lds_all + PassLds<DNERF, TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS;
     float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    float* lds = lds_all + PassLds<TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
+    float* lds = lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
     float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
     float* cdf = lds + 2 * SW_LDS_SC;            // [S-1]
@@ -157,7 +160,34 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         f32x16 emb[2], in[8], out[8];
         float head[3], rgb[3];
         pe_pos(px, py, pz, h, emb);
-        if (DNERF) {
+        if (DNERF && TRAIN) {
+            // deformation net, then the canonical net on gamma(x + dx) (model.py:128-151); both save what their dX
+            // chains and weight-gradient GEMMs need, as side stores (see the static branch below).  Always both passes:
+            // the t == 0 / zero_canonical case trains the canonical net alone through the static kernel.
+            const int64_t tix = ray * ntiles + tile, prow = tix * 32 + j;
+            float* act_row = P.act + prow * SW_ACT_LD + 4 * h;
+            float* mask_tile = P.bits + tix * SW_MASK_TILE_FLOATS + lane * 4;
+            float* xs_row = P.xs + prow * SW_XS_LD + 4 * h;
+            f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+            trunk_pass<true, true, true>(emb, lds_emb, ft, true, h, in, out, head, ws, P.act_d + prow * SW_ACT_LD + 4 * h,
+                                         P.bits_d + tix * SW_MASK_TILE_FLOATS + lane * 4, true, nullptr, P.xs_d + prow * SW_XS_LD + 4 * h);
+            const float ex = head[0], ey = head[1], ez = head[2];
+            if (live && h == 0) {
+                float* o = a.dx + (ray * S + s) * 3;
+                o[0] = ex; o[1] = ey; o[2] = ez;
+            }
+            px = px + ex; py = py + ey; pz = pz + ez;
+            pe_pos(px, py, pz, h, emb);
+            f32x16 demb;
+            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {demb[4 * g], demb[4 * g + 1], demb[4 * g + 2], demb[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
+            }
+            trunk_pass<true, true, true>(emb, lds_emb, ft, false, h, in, out, head, ws, act_row, mask_tile, false, &mb, xs_row);
+            canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+        } else if (DNERF) {
 #pragma nounroll
             for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
                 trunk_pass<true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws);

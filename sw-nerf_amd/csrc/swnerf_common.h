@@ -70,6 +70,11 @@
 #define SW_BWD_IG_STEPS (SW_BWD_STEPS + 2 * 64)
 #define SW_BWD_IG_W_FLOATS ((SW_BWD_IG_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_BWD_IG_FLOATS (SW_BWD_IG_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// fused D-NeRF backward (render_pass_backward_kernel<true>): the input-gradient canonical stream, then the deformation
+// stream, ONE ring; bias tiles: alpha_linear.weight (8) then _time_out.weight rows (24)
+#define SW_BWD_DN_STEPS (SW_BWD_IG_STEPS + 7 * 256)
+#define SW_BWD_DN_W_FLOATS ((SW_BWD_DN_STEPS + SW_TAIL) * SW_STEP_FLOATS)
+#define SW_BWD_DN_FLOATS (SW_BWD_DN_W_FLOATS + (SW_BWD_BIAS_TILES + 24) * SW_BIAS_TILE_FLOATS)
 // deformation net (`_time`): L7^T .. L1^T (trunk columns); then _time_out.weight [3,256] as 3 x 8 bias tiles
 #define SW_DBWD_STEPS (7 * 256)
 #define SW_DBWD_W_FLOATS ((SW_DBWD_STEPS + SW_TAIL) * SW_STEP_FLOATS)

@@ -220,17 +220,23 @@ __global__ void __launch_bounds__(256, 1) deform_backward_dx_kernel(DeformBwdDev
 #define PB_SMAX 256
 #define PB_WAVE_FLOATS (6 * PB_SMAX)                 // T[S], w[S], d_raw[S][4]
 struct PassBwdDev {
-    const float* w0; const float* b0;                // backward stream (SWNERF_BWD_CANON); its 8 "bias" tiles = alpha_linear.weight
+    const float* w0; const float* b0;                // backward stream; bias tiles: alpha_linear.weight (8) [, _time_out.weight rows (24)]
     const float* bits;                               // [n_rays * ntiles, SW_MASK_TILE_FLOATS]
     const float* raw; const float* z; const float* ray_batch; int cols; const float* noise;
     int64_t n_rays; int S; int white;
     const float* g_rgb; const float* g_disp; const float* g_acc;
+    const float* g_raw;                              // upstream gradient of the returned raw [N,S,4] (retraw) or NULL: added to d raw
     float* grad; float* d_raw;                       // [rows, SW_ACT_LD], [rows, 4]
+    // D-NeRF: the deformation net's masks, the saved dx = position_delta [N,S,3], its upstream gradient (or NULL),
+    // the position-encoding band count, and the outputs grad_d [rows, SW_ACT_LD], g_dx [rows, 4] (= d dx, 4th column 0)
+    const float* bits_d; const float* dx; const float* g_pd; int Lp;
+    float* grad_d; float* g_dx;
 };
 
+template <bool DNERF>
 __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev P) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
-    constexpr int BIASF = SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    constexpr int BIASF = (DNERF ? SW_BWD_BIAS_TILES + SW_DBWD_BIAS_TILES : SW_BWD_BIAS_TILES) * SW_BIAS_TILE_FLOATS;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
     const int S = P.S;
     const int ntiles = (S + 31) >> 5;
     const float* rb = P.ray_batch + ray * P.cols;
-    const float ddx = rb[3], ddy = rb[4], ddz = rb[5];
+    const float rox = rb[0], roy = rb[1], roz = rb[2], ddx = rb[3], ddy = rb[4], ddz = rb[5];
     const float dnorm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     const float* zv = P.z + ray * S;
     const float* raw = P.raw + ray * S * 4;
@@ -319,15 +325,17 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
     }
     wave_lds_sync();
 
-    // ---- 2. the dX chain, tile by tile (mlp_backward_dx_kernel<false>)
+    // ---- 2. the dX chain(s), tile by tile: mlp_backward_dx_kernel<DNERF> [+ deform_backward_dx_kernel]
     const f32x4 nomask = {0.f, 0.f, 0.f, 0.f};
 #pragma nounroll
     for (int tile = 0; tile < ntiles; ++tile) {
         const int s = tile * 32 + j;
         const bool live = s < S;
+        const int sc = live ? s : S - 1;
         const int64_t tix = ray * ntiles + tile;
         const int64_t prow = tix * 32 + j;
-        f32x4 dr = *reinterpret_cast<const f32x4*>(dR + 4 * (live ? s : S - 1));
+        f32x4 dr = *reinterpret_cast<const f32x4*>(dR + 4 * sc);
+        if (P.g_raw) dr += *reinterpret_cast<const f32x4*>(P.g_raw + (ray * S + sc) * 4);
         if (!live) dr = nomask;
         if (h == 0) *reinterpret_cast<f32x4*>(P.d_raw + prow * 4) = dr;
         float* grad_row = P.grad + prow * SW_ACT_LD + 4 * h;
@@ -351,12 +359,70 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
             for (int n = 0; n < 8; ++n) in[n] = out[n];
             mask_apply<8>(mask_take(mr), in);
             mask_fetch(mr, l - 1);
+            if (DNERF && l == 5) {                                           // the skip input cat[gamma(x+dx), h4]: its gamma part
+                f32x16 ge[2];
+                seg_mfma<2, 8, SEG_ZERO>(ge, in, ws);
+                emb_park(lds_emb, lane, ge);
+            }
             seg_mfma<8, 8, SEG_ZERO, 8>(out, in, ws, 1.f, SideStore{grad_row + 256 * l, nullptr, nomask});
         }
 #pragma unroll
         for (int n = 0; n < 8; ++n) in[n] = out[n];
         mask_apply<8>(mask_take(mr), in);                                    // d pre_0
-        tiles_store<8>(grad_row, in);
+        if (!DNERF) {
+            tiles_store<8>(grad_row, in);
+        } else {
+            // d gamma(x+dx) -> d(x+dx) through the sin/cos Jacobian (mlp_backward_dx_kernel<true>), + the upstream gradient of
+            // position_delta (the TV loss's operand, run_dnerf.py:700-716) = d dx: the seed of the deformation net's chain
+            mask_start(mr, P.bits_d, tix, lds_emb + 2 * 16 * 64, lane);
+            mask_fetch(mr, 7);                                               // h7 of the deformation net; taken after the next segment
+            f32x16 ge[2];
+            emb_fetch(lds_emb, lane, ge);
+            seg_mfma<2, 8, SEG_ACC, 8>(ge, in, ws, 1.f, SideStore{grad_row, nullptr, nomask});
+            const float z = zv[sc];
+            const float* dxs = P.dx + (ray * S + sc) * 3;
+            const float x0 = rox + ddx * z + dxs[0], x1 = roy + ddy * z + dxs[1], x2 = roz + ddz * z + dxs[2];   // x + dx, as the forward formed it
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 30; ++a) {
+                const int k = a / 3, c = a % 3;
+                const float f = (float)(1 << k);
+                const float xc = (c == 0) ? x0 : ((c == 1) ? x1 : x2);
+                float d = sw_sin_or_cos(xc * f, 1 - h) * f;                  // d sin = cos, d cos = -sin
+                d = h ? -d : d;
+                const float t = (k < P.Lp) ? ge[a >> 4][a & 15] * d : 0.f;
+                if (c == 0) g0 += t; else if (c == 1) g1 += t; else g2 += t;
+            }
+            if (h == 0) { g0 += ge[1][14]; g1 += ge[1][15]; } else { g2 += ge[1][14]; }
+            g0 += __shfl_xor(g0, 32, 64); g1 += __shfl_xor(g1, 32, 64); g2 += __shfl_xor(g2, 32, 64);
+            if (P.g_pd) { const float* gp = P.g_pd + (ray * S + sc) * 3; g0 += gp[0]; g1 += gp[1]; g2 += gp[2]; }
+            if (!live) { g0 = 0.f; g1 = 0.f; g2 = 0.f; }
+            if (h == 0) { f32x4 g4 = {g0, g1, g2, 0.f}; *reinterpret_cast<f32x4*>(P.g_dx + prow * 4) = g4; }
+            // d h7 = _time_out.weight^T . d dx  (24 bias-style tiles right behind alpha_linear's 8), then _time.7 .. _time.1
+            float* gd_row = P.grad_d + prow * SW_ACT_LD + 4 * h;
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws.bias + (0 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(ws.bias + (1 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(ws.bias + (2 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[n][4 * g + e] = w0[e] * g0 + w1[e] * g1 + w2[e] * g2;
+                }
+#pragma nounroll
+            for (int l = 7; l >= 1; --l) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) in[n] = out[n];
+                mask_apply<8>(mask_take(mr), in);
+                mask_fetch(mr, l - 1);
+                seg_mfma<8, 8, SEG_ZERO, 8>(out, in, ws, 1.f, SideStore{gd_row + 256 * l, nullptr, nomask});
+            }
+#pragma unroll
+            for (int n = 0; n < 8; ++n) in[n] = out[n];
+            mask_apply<8>(mask_take(mr), in);                                // d pre_0 of the deformation net (x, t are data)
+            tiles_store<8>(gd_row, in);
+        }
         ws_rewind(ws, P.w0, lds_all, lane);
     }
 }
@@ -444,7 +510,8 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     const swnerf_pass_args& a = *args;
     if (a.n_rays == 0 && a.packed) return 0;
     if (!a.packed || !a.ray_batch || !act || !bits || !xs) return sw_fail(SWNERF_E_ARG, "render_pass_train: NULL pointer");
-    if (a.kind != SWNERF_NET_CANON || a.cols != 11) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: the static net with an 11-column ray batch only");
+    if (a.kind != SWNERF_NET_CANON || (a.cols != 11 && a.cols != 12))
+        return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: the static net (SWNERF_NET_CANON) with an 11- or 12-column ray batch");
     if (a.n_rays < 0 || a.n_samples < 2 || a.n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: 2 <= n_samples <= %d (got %d)", PB_SMAX, a.n_samples);
     if (!a.raw || !(a.z_vals || a.z_out)) return sw_fail(SWNERF_E_ARG, "render_pass_train: the backward needs raw and the depths (z_vals given or z_out)");
     if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: embedder bands (%d,%d) exceed (10,4)", a.L_pos, a.L_dir);
@@ -454,9 +521,9 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     P.a = a;
     int rc = stream_ptrs(a.kind, a.packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
-    P.act = act; P.bits = bits; P.xs = xs;
+    P.act = act; P.bits = bits; P.xs = xs; P.act_d = nullptr; P.bits_d = nullptr; P.xs_d = nullptr;
     P.sort_n = 0; P.sort_s = 0;
-    size_t lds = PassLds<true>::FIXED * sizeof(float);
+    size_t lds = PassLds<false, true>::FIXED * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine) return sw_fail(SWNERF_E_ARG, "render_pass_train: n_importance>0 needs z_fine");
         if (a.n_samples < 3 || a.n_samples > SW_LDS_SC || a.n_samples + a.n_importance > SW_LDS_SORT)
@@ -477,7 +544,7 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
 extern "C" int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, const float* raw, const float* z_vals,
                                            const float* ray_batch, int cols, const float* noise, int64_t n_rays, int n_samples,
                                            int white_bkgd, const float* g_rgb, const float* g_disp, const float* g_acc,
-                                           float* grad, float* d_raw, void* stream) {
+                                           const float* g_raw, float* grad, float* d_raw, void* stream) {
     if (n_rays == 0 && packed_bwd) return 0;
     if (!packed_bwd || !bits || !raw || !z_vals || !ray_batch || !grad || !d_raw || n_rays < 0)
         return sw_fail(SWNERF_E_ARG, "render_pass_backward: NULL pointer or negative n_rays");
@@ -486,9 +553,58 @@ extern "C" int swnerf_render_pass_backward(const float* packed_bwd, const float*
     PassBwdDev P;
     P.w0 = packed_bwd; P.b0 = packed_bwd + SW_BWD_W_FLOATS; P.bits = bits; P.raw = raw; P.z = z_vals; P.ray_batch = ray_batch;
     P.cols = cols; P.noise = noise; P.n_rays = n_rays; P.S = n_samples; P.white = white_bkgd;
-    P.g_rgb = g_rgb; P.g_disp = g_disp; P.g_acc = g_acc; P.grad = grad; P.d_raw = d_raw;
+    P.g_rgb = g_rgb; P.g_disp = g_disp; P.g_acc = g_acc; P.g_raw = g_raw; P.grad = grad; P.d_raw = d_raw;
     const size_t lds = (SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
-    hipLaunchKernelGGL(render_pass_backward_kernel, grid, block, lds, (hipStream_t)stream, P);
+    P.bits_d = nullptr; P.dx = nullptr; P.g_pd = nullptr; P.Lp = 0; P.grad_d = nullptr; P.g_dx = nullptr;
+    hipLaunchKernelGGL(render_pass_backward_kernel<false>, grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_backward launch");
+}
+
+// ---- the same for DirectTemporalNeRF at t != 0 (model.py:128-151; loss of d_nerf/run_dnerf.py:690-725) ----------------
+extern "C" int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args, float* act, float* bits, float* xs,
+                                              float* act_d, float* bits_d, float* xs_d, void* stream) {
+    if (!args) return sw_fail(SWNERF_E_ARG, "render_pass_train_dnerf: NULL args");
+    const swnerf_pass_args& a = *args;
+    if (a.n_rays == 0 && a.packed) return 0;
+    if (!a.packed || !a.ray_batch || !act || !bits || !xs || !act_d || !bits_d || !xs_d) return sw_fail(SWNERF_E_ARG, "render_pass_train_dnerf: NULL pointer");
+    if (a.kind != SWNERF_NET_DNERF || a.cols != 12 || !a.run_deform)
+        return sw_fail(SWNERF_E_UNSUPP, "render_pass_train_dnerf: DirectTemporalNeRF with the deformation pass (t != 0) and a 12-column ray batch");
+    if (a.n_rays < 0 || a.n_samples < 2 || a.n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train_dnerf: 2 <= n_samples <= %d (got %d)", PB_SMAX, a.n_samples);
+    if (a.n_importance != 0) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train_dnerf: no resampling in the training pass (give the depths)");
+    if (!a.raw || !a.dx || !(a.z_vals || a.z_out)) return sw_fail(SWNERF_E_ARG, "render_pass_train_dnerf: the backward needs raw, dx and the depths (z_vals given or z_out)");
+    if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4 || a.L_time < 0 || a.L_time > 10)
+        return sw_fail(SWNERF_E_UNSUPP, "render_pass_train_dnerf: embedder bands (%d,%d,%d) exceed (10,4,10)", a.L_pos, a.L_dir, a.L_time);
+    if (a.z_vals && a.t_rand) return sw_fail(SWNERF_E_ARG, "render_pass_train_dnerf: t_rand only applies to coarse sampling");
+    PassDev P;
+    P.a = a;
+    int rc = stream_ptrs(a.kind, a.packed, 1, &P.w0, &P.b0, &P.nbias, &P.two_pass);
+    if (rc) return rc;
+    P.act = act; P.bits = bits; P.xs = xs; P.act_d = act_d; P.bits_d = bits_d; P.xs_d = xs_d;
+    P.sort_n = 0; P.sort_s = 0;
+    const size_t lds = PassLds<true, true>::FIXED * sizeof(float);
+    const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
+    hipLaunchKernelGGL((render_pass_kernel<true, true>), grid, block, lds, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "render_pass_train_dnerf launch");
+}
+
+extern "C" int swnerf_render_pass_backward_dnerf(const float* packed_bwd_fused, const float* bits, const float* bits_d, const float* raw,
+                                                 const float* z_vals, const float* ray_batch, int cols, const float* noise,
+                                                 const float* dx, const float* g_position_delta, int64_t n_rays, int n_samples,
+                                                 int white_bkgd, int L_pos, const float* g_rgb, const float* g_disp, const float* g_acc,
+                                                 const float* g_raw, float* grad, float* grad_d, float* d_raw, float* g_dx, void* stream) {
+    if (n_rays == 0 && packed_bwd_fused) return 0;
+    if (!packed_bwd_fused || !bits || !bits_d || !raw || !z_vals || !ray_batch || !dx || !grad || !grad_d || !d_raw || !g_dx || n_rays < 0)
+        return sw_fail(SWNERF_E_ARG, "render_pass_backward_dnerf: NULL pointer or negative n_rays");
+    if (n_samples < 2 || n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_backward_dnerf: 2 <= n_samples <= %d (got %d)", PB_SMAX, n_samples);
+    if (cols < 8 || L_pos < 0 || L_pos > 10) return sw_fail(SWNERF_E_ARG, "render_pass_backward_dnerf: cols %d / L_pos %d", cols, L_pos);
+    PassBwdDev P;
+    P.w0 = packed_bwd_fused; P.b0 = packed_bwd_fused + SW_BWD_DN_W_FLOATS; P.bits = bits; P.raw = raw; P.z = z_vals; P.ray_batch = ray_batch;
+    P.cols = cols; P.noise = noise; P.n_rays = n_rays; P.S = n_samples; P.white = white_bkgd;
+    P.g_rgb = g_rgb; P.g_disp = g_disp; P.g_acc = g_acc; P.g_raw = g_raw; P.grad = grad; P.d_raw = d_raw;
+    P.bits_d = bits_d; P.dx = dx; P.g_pd = g_position_delta; P.Lp = L_pos; P.grad_d = grad_d; P.g_dx = g_dx;
+    const size_t lds = ((SW_BWD_BIAS_TILES + SW_DBWD_BIAS_TILES) * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    hipLaunchKernelGGL(render_pass_backward_kernel<true>, grid, block, lds, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "render_pass_backward_dnerf launch");
 }

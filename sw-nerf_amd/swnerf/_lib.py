@@ -18,8 +18,9 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
            "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
+           "swnerf_render_pass_train_dnerf", "swnerf_render_pass_backward_dnerf", "swnerf_unslot_grad_time",
            "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask"]
-BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM = 0, 1, 2
+BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM, BWD_DNERF_FUSED = 0, 1, 2, 3
 
 
 class PassArgs(Structure):
@@ -98,7 +99,10 @@ def lib():
     L.swnerf_xs_floats_per_row.argtypes = []
     L.swnerf_render_pass_train.argtypes = [POINTER(PassArgs), c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_render_pass_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
-                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_render_pass_train_dnerf.argtypes = [POINTER(PassArgs)] + [c_void_p] * 7
+    L.swnerf_render_pass_backward_dnerf.argtypes = [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int] + [c_void_p] * 9
+    L.swnerf_unslot_grad_time.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
     L.swnerf_unslot_grad.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
     L.swnerf_linear.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
     L.swnerf_gemm_nn.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]

@@ -148,6 +148,37 @@ def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g):
                                         col0, st), "unslot_grad")
 
 
+def _deform_slot_buffers(device):
+    """Zeroed slot-ordered accumulators for the deformation net's encoding GEMMs (gamma(x) of `_time.0` and `_time.5`,
+    gamma(t) of `_time.0`) and the 4-row form of `_time_out`'s gradient."""
+    z = torch.zeros(256 * 64 + 256 * 64 + 256 * 32 + 4 * 256 + 4, dtype=torch.float32, device=device)
+    return (z[:16384].view(256, 64), z[16384:32768].view(256, 64), z[32768:40960].view(256, 32),
+            z[40960:41984].view(4, 256), z[41984:41988])
+
+
+def _deform_weight_grads_slots(L, st, M, grad_d, act_d, xs_d, g_dx, Cpos, gd, bufs):
+    """dW / db of the deformation net (`_time.0..7`, `_time_out`; gd: zeroed tensors in _DEFORM_ORDER) for the fused D-NeRF
+    training pass, accumulating (one call per row chunk): xs_d [M, 96] = gamma(x) (64 slots) and gamma(t) (32 slots) in
+    operand slot order, g_dx [M, 4] = d dx with a zero 4th column (aligned: the 4-row form, 4th row dropped)."""
+    c0s, c5s, cts, w4, b4 = bufs
+    mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
+    mm(grad_d, 0, 256, xs_d, 0, 64, c0s, 0, gd[1])                             # _time.0 = [gamma(x) | gamma(t)]
+    mm(grad_d, 0, 256, xs_d, 64, 32, cts, 0, None)
+    for l in (1, 2, 3, 4, 6, 7):
+        mm(grad_d, 256 * l, 256, act_d, 256 * (l - 1), 256, gd[2 * l], 0, gd[2 * l + 1])
+    _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=xs_d, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # _time.5
+    mm(g_dx, 0, 4, act_d, 1792, 256, w4, 0, b4)                                # _time_out (rows 0..2)
+
+
+def _deform_unslot(L, st, bufs, Lp, Lt, Cpos, gd):
+    c0s, c5s, cts, w4, b4 = bufs
+    for cs, W in ((c0s, gd[0]), (c5s, gd[10])):
+        _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), 64, 256, 0, 64, Lp, 0, W.data_ptr(), W.stride(0), 0, st), "unslot_grad")
+    _lib.check(L.swnerf_unslot_grad_time(_lib.ptr(cts), 32, 256, 32, Lt, gd[0].data_ptr(), gd[0].stride(0), Cpos, st), "unslot_grad_time")
+    gd[16] = gd[16] + w4[:3]
+    gd[17] = gd[17] + b4[:3]
+
+
 class _MlpTrain(torch.autograd.Function):
     """Differentiable forward of the static 8x256 net: the forward kernel saves
     every layer's activation; backward = the register-resident dX chain over the transposed weight
@@ -279,7 +310,7 @@ class _PackedMixin:
         """A transposed weight stream of the backward dX chains (include/swnerf.h SWNERF_BWD_*), cached like packed()."""
         kind, names, Lp, Ld, Lt = self._pack_params()
         sd = dict(self.named_parameters())
-        ps = [sd[n] for n in (_DEFORM_ORDER if bwd_kind == _lib.BWD_DEFORM else names[:24])]
+        ps = [sd[n] for n in (_DEFORM_ORDER if bwd_kind == _lib.BWD_DEFORM else (names if bwd_kind == _lib.BWD_DNERF_FUSED else names[:24]))]
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if self._pack_bwd.get(bwd_kind, (None, None))[0] != key:
             L = _lib.lib()

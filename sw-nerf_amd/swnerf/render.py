@@ -195,10 +195,12 @@ class _FusedPassTrain(torch.autograd.Function):
         ctx.has_noise = noise is not None
         ctx.save_for_backward(rb, z, raw, act, bits, xs, noise if noise is not None else new(0), *params)
         ctx.mark_non_differentiable(z_fine, z_std)
-        return rgb, disp, acc, z_fine, z_std
+        # raw is an output as well (retraw=True is what the reference's train() passes, nerf/run.py:685): a gradient
+        # arriving on it is added to d raw in the backward kernel
+        return rgb, disp, acc, z_fine, z_std, raw
 
     @staticmethod
-    def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs):
+    def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
         from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
@@ -207,7 +209,7 @@ class _FusedPassTrain(torch.autograd.Function):
         N, cols = rb.shape
         st = _lib.stream_of(rb)
         c = lambda g: None if g is None else g.contiguous().float()
-        g_rgb, g_disp, g_acc = c(g_rgb), c(g_disp), c(g_acc)
+        g_rgb, g_disp, g_acc, g_raw = c(g_rgb), c(g_disp), c(g_acc), c(g_raw)
         g = _zero_grads(params)
         slot_bufs, rgb4 = _slot_buffers(rb.device), _rgb4_buffers(rb.device)
         # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
@@ -226,7 +228,8 @@ class _FusedPassTrain(torch.autograd.Function):
             _lib.check(L.swnerf_render_pass_backward(
                 _lib.ptr(packed_bwd), _lib.ptr(bits[r0 * mask_per_ray:r1 * mask_per_ray]), _lib.ptr(raw[r0:r1]), _lib.ptr(z[r0:r1]),
                 _lib.ptr(rb[r0:r1]), cols, _lib.ptr(noise[r0:r1]) if ctx.has_noise else None, n, S, int(ctx.white),
-                _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(grad), _lib.ptr(d_raw), st),
+                _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)),
+                _lib.ptr(grad), _lib.ptr(d_raw), st),
                 "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
             _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
@@ -237,7 +240,7 @@ class _FusedPassTrain(torch.autograd.Function):
 
 def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
                       n_importance=0, u=None):
-    """One differentiable fused pass (`_FusedPassTrain`): dict with rgb_map disp_map acc_map (+ z_fine z_std)."""
+    """One differentiable fused pass (`_FusedPassTrain`): dict with rgb_map disp_map acc_map raw (+ z_fine z_std)."""
     from .model import _CANON_ORDER
     rb = _lib.dev_f32(ray_batch.detach(), "ray_batch")
     N, S = rb.shape[0], int(n_samples)
@@ -247,9 +250,9 @@ def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, 
         if t is not None and t.shape[0] != N:
             raise ValueError(f"swnerf.render_pass_train: {name} must have {N} rows, got {tuple(t.shape)}")
     sd = dict(net.named_parameters())
-    rgb, disp, acc, z_fine, z_std = _FusedPassTrain.apply(net, rb, z_vals, S, bool(lindisp), t_rand, noise, bool(white_bkgd),
-                                                          int(n_importance), u, *[sd[n] for n in _CANON_ORDER])
-    out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc}
+    rgb, disp, acc, z_fine, z_std, raw = _FusedPassTrain.apply(net, rb, z_vals, S, bool(lindisp), t_rand, noise, bool(white_bkgd),
+                                                               int(n_importance), u, *[sd[n] for n in _CANON_ORDER])
+    out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "raw": raw}
     if n_importance > 0:
         out["z_fine"], out["z_std"] = z_fine, z_std
     return out
@@ -290,9 +293,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     plan = fused_plan(network_query_fn, [network_fn, network_fine], allow_train=True) if ray_batch.shape[-1] == 11 else None
     training = wants_grad([network_fn, network_fine])
     if plan is not None and training:
-        # the fused pass has a backward for the static nets, up to 256 samples per pass, when `raw` is not asked for
-        # (a returned raw would need a gradient path of its own); anything else trains on the differentiable op path
-        ok = (not retraw and ray_batch.shape[0] > 0 and N_samples <= TRAIN_FUSED_MAX_SAMPLES
+        # the fused pass has a backward for the static nets, up to 256 samples per pass; anything else trains on the
+        # differentiable op path
+        ok = (ray_batch.shape[0] > 0 and N_samples <= TRAIN_FUSED_MAX_SAMPLES
               and N_samples + max(0, N_importance) <= TRAIN_FUSED_MAX_SAMPLES and os.environ.get("SWNERF_TRAIN_OP_PATH") != "1"
               and all(net is None or isinstance(net, vallina_NeRF) for net in (network_fn, network_fine)))
         if not ok:
@@ -306,12 +309,18 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         p0 = render_pass_train(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
                                white_bkgd=white_bkgd, n_importance=max(0, N_importance), u=u)
         if N_importance <= 0:
-            return {'rgb_map': p0["rgb_map"], 'disp_map': p0["disp_map"], 'acc_map': p0["acc_map"]}
+            ret = {'rgb_map': p0["rgb_map"], 'disp_map': p0["disp_map"], 'acc_map': p0["acc_map"]}
+            if retraw:
+                ret['raw'] = p0["raw"]
+            return ret
         S1 = N_samples + N_importance
         run_fn = network_fn if network_fine is None else network_fine
         p1 = render_pass_train(ray_batch, run_fn, S1, z_vals=p0["z_fine"], noise=noise(S1), white_bkgd=white_bkgd)
-        return {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"],
-                'rgb0': p0["rgb_map"], 'disp0': p0["disp_map"], 'acc0': p0["acc_map"], 'z_std': p0["z_std"]}
+        ret = {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"]}
+        if retraw:
+            ret['raw'] = p1["raw"]
+        ret.update({'rgb0': p0["rgb_map"], 'disp0': p0["disp_map"], 'acc0': p0["acc_map"], 'z_std': p0["z_std"]})
+        return ret
     want = ["rgb_map", "disp_map", "acc_map"] + (["raw"] if (retraw and N_importance <= 0) else [])
     p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
                      white_bkgd=white_bkgd, want=want, n_importance=max(0, N_importance), u=u)

@@ -69,6 +69,162 @@ def _single_time(ray_batch):
     return lo
 
 
+class _FusedPassTrainDnerf(torch.autograd.Function):
+    """The fused D-NeRF pass under autograd (DirectTemporalNeRF at t != 0, model.py:128-151; the loss of
+    d_nerf/run_dnerf.py:690-725 puts gradients on the image and on position_delta).  forward =
+    swnerf_render_pass_train_dnerf: deformation net -> x + dx -> canonical net -> compositing in one kernel, saving both
+    nets' activations / masks / encodings as side stores; backward = swnerf_render_pass_backward_dnerf: per ray the
+    compositing backward, then per tile the canonical dX chain incl. d gamma(x+dx) -> d(x+dx) through the sin/cos
+    Jacobian, + the upstream gradient of position_delta, then the deformation net's dX chain - ONE weight ring over both
+    transposed streams; then one TN GEMM per Linear layer of both nets."""
+
+    @staticmethod
+    def forward(ctx, net, rb, z_vals, S, lindisp, t_rand, noise, white_bkgd, *params):
+        kind, packed, Lp, Ld, Lt = net.packed()
+        L = _lib.lib()
+        N, cols = rb.shape
+        dev = rb.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        rows = L.swnerf_train_rows(N, S)
+        nact, nxs, nbits = L.swnerf_act_floats_per_row(), L.swnerf_xs_floats_per_row(), L.swnerf_mask_floats(rows)
+        act, bits, xs = new(rows, nact), new(nbits), new(rows, nxs)
+        act_d, bits_d, xs_d = new(rows, nact), new(nbits), new(rows, nxs)
+        raw, rgb, disp, acc, dx = new(N, S, 4), new(N, 3), new(N), new(N), new(N, S, 3)
+        a = _lib.PassArgs()
+        a.ray_batch, a.n_rays, a.cols, a.kind, a.packed = rb.data_ptr(), N, cols, kind, packed.data_ptr()
+        a.run_deform, a.L_pos, a.L_dir, a.L_time, a.n_samples = 1, Lp, Ld, Lt, S
+        a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
+        a.rgb_map, a.disp_map, a.acc_map, a.raw, a.dx = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), raw.data_ptr(), dx.data_ptr()
+        if z_vals is not None:
+            z = z_vals
+            a.z_vals = z.data_ptr()
+        else:
+            z = new(N, S)
+            a.z_out = z.data_ptr()
+        for name, t in (("t_rand", t_rand), ("noise", noise)):
+            if t is not None:
+                setattr(a, name, t.data_ptr())
+        _lib.check(L.swnerf_render_pass_train_dnerf(a, _lib.ptr(act), _lib.ptr(bits), _lib.ptr(xs), _lib.ptr(act_d), _lib.ptr(bits_d),
+                                                    _lib.ptr(xs_d), _lib.stream_of(rb)), "render_pass_train_dnerf")
+        ctx.net, ctx.S, ctx.white, ctx.bands = net, S, bool(white_bkgd), (Lp, Ld, Lt)
+        ctx.has_noise = noise is not None
+        ctx.save_for_backward(rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise if noise is not None else new(0), *params)
+        ctx.mark_non_differentiable(z)
+        return rgb, disp, acc, dx, z, raw
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
+        from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
+                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot)
+        from .render import TRAIN_BWD_CHUNK_ROWS
+        from . import render as _r
+        rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
+        net, S = ctx.net, ctx.S
+        Lp, Ld, Lt = ctx.bands
+        L = _lib.lib()
+        N, cols = rb.shape
+        st = _lib.stream_of(rb)
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_rgb, g_disp, g_acc, g_dx_up, g_raw = c(g_rgb), c(g_disp), c(g_acc), c(g_dx_up), c(g_raw)
+        g = _zero_grads(params)                                   # 24 `_occ` tensors then 18 `_time` / `_time_out`
+        slot_bufs, rgb4, dbufs = _slot_buffers(rb.device), _rgb4_buffers(rb.device), _deform_slot_buffers(rb.device)
+        rows_per_ray = act.shape[0] // N
+        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // 2 // rows_per_ray) // 4 * 4)     # two gradient buffers alive per chunk
+        packed_bwd = net.packed_bwd(_lib.BWD_DNERF_FUSED)
+        mask_per_ray = bits.numel() // N
+        sl = lambda t, r0, r1: None if t is None else t[r0:r1]
+        nrow = min(N, chunk) * rows_per_ray
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=rb.device)
+        grad, grad_d, d_raw, g_dx = new(nrow, act.shape[1]), new(nrow, act.shape[1]), new(nrow, 4), new(nrow, 4)
+        gc, gd = g[:24], g[24:]
+        Cpos, Cdir = net.input_ch, net.input_ch_views
+        for r0 in range(0, N, chunk):
+            r1 = min(N, r0 + chunk)
+            n, m = r1 - r0, (r1 - r0) * rows_per_ray
+            b0, b1 = r0 * mask_per_ray, r1 * mask_per_ray
+            _lib.check(L.swnerf_render_pass_backward_dnerf(
+                _lib.ptr(packed_bwd), _lib.ptr(bits[b0:b1]), _lib.ptr(bits_d[b0:b1]), _lib.ptr(raw[r0:r1]), _lib.ptr(z[r0:r1]),
+                _lib.ptr(rb[r0:r1]), cols, _lib.ptr(noise[r0:r1]) if ctx.has_noise else None, _lib.ptr(dx[r0:r1]),
+                _lib.ptr(sl(g_dx_up, r0, r1)), n, S, int(ctx.white), Lp, _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)),
+                _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)), _lib.ptr(grad), _lib.ptr(grad_d), _lib.ptr(d_raw), _lib.ptr(g_dx), st),
+                "render_pass_backward_dnerf")
+            a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
+            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4)
+            _deform_weight_grads_slots(L, st, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs)
+        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc)
+        _rgb4_finish(gc, rgb4)
+        _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)
+        g = gc + gd
+        return (None,) * 8 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
+
+
+def _render_pass_train_dnerf(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False):
+    """One differentiable fused D-NeRF pass: dict with rgb_map disp_map acc_map dx z raw."""
+    rb = _lib.dev_f32(ray_batch.detach(), "ray_batch")
+    N, S = rb.shape[0], int(n_samples)
+    chk = lambda t, name: None if t is None else _lib.dev_f32(t.detach(), name, S)
+    z_vals, t_rand, noise = chk(z_vals, "z_vals"), chk(t_rand, "t_rand"), chk(noise, "noise")
+    kind, names, Lp, Ld, Lt = net._pack_params()
+    sd = dict(net.named_parameters())
+    rgb, disp, acc, dx, z, raw = _FusedPassTrainDnerf.apply(net, rb, z_vals, S, bool(lindisp), t_rand, noise, bool(white_bkgd),
+                                                           *[sd[n] for n in names])
+    return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "dx": dx, "z": z, "raw": raw}
+
+
+def _render_rays_train_fused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb, N_importance,
+                             network_fine, white_bkgd, raw_noise_std, pytest, z_vals, use_two_models_for_fine):
+    """render_rays under autograd on the fused kernels, or None when this case is not covered (-> the op path).
+    Covered: ONE model for both passes (the shipped D-NeRF configs: use_two_models_for_fine False, so the coarse pass
+    only feeds the resampling and runs under no_grad, run_dnerf.py:417-421), N_importance = 0, or external z_vals; a
+    DirectTemporalNeRF at t != 0 -> the fused D-NeRF training pass, at t == 0 with zero_canonical (model.py:143-145) or a
+    NeRFOriginal -> the static fused training pass on the canonical net, position_delta = 0."""
+    from .render import render_pass_train, TRAIN_FUSED_MAX_SAMPLES, wants_grad
+    from .model import NeRFOriginal
+    run_fn = network_fn if network_fine is None else network_fine
+    N = ray_batch.shape[0]
+    if (os.environ.get("SWNERF_TRAIN_OP_PATH") == "1" or N == 0 or ray_batch.shape[-1] != 12
+            or (N_importance > 0 and z_vals is None and use_two_models_for_fine)
+            or not isinstance(run_fn, (DirectTemporalNeRF, NeRFOriginal)) or not wants_grad([run_fn])):
+        return None
+    S1 = (z_vals.shape[-1] if z_vals is not None else N_samples + max(0, N_importance))
+    if S1 > TRAIN_FUSED_MAX_SAMPLES or N_samples > TRAIN_FUSED_MAX_SAMPLES:
+        return None
+    t0 = _single_time(ray_batch)
+    deform = lambda net: isinstance(net, DirectTemporalNeRF) and not (t0 == 0. and net.zero_canonical)
+    t_rand, u, noise = _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
+    z_std = None
+    if z_vals is None and N_importance > 0:
+        with torch.no_grad():                                    # the resampling pass: inference kernel (run_dnerf.py:417-421)
+            p0 = render_pass(ray_batch.detach(), network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
+                             white_bkgd=white_bkgd, want=[], n_importance=N_importance, u=u, run_deform=deform(network_fn))
+        z_in, z_std, t_rand = p0["z_fine"], p0["z_std"], None
+    else:
+        z_in = None if z_vals is None else _lib.dev_f32(z_vals, "z_vals")
+        if z_in is not None:
+            t_rand = None
+    if deform(run_fn):
+        p1 = _render_pass_train_dnerf(ray_batch, run_fn, S1, z_vals=z_in, lindisp=lindisp, t_rand=t_rand, noise=noise(S1), white_bkgd=white_bkgd)
+        z_final, pd = p1["z"], p1["dx"]
+    else:
+        canon = run_fn._occ if isinstance(run_fn, DirectTemporalNeRF) else run_fn
+        p1 = render_pass_train(ray_batch, canon, S1, z_vals=z_in, lindisp=lindisp, t_rand=t_rand, noise=noise(S1), white_bkgd=white_bkgd)
+        if z_in is None:
+            with torch.no_grad():
+                z_in = sample_coarse_z(ray_batch, S1, lindisp, t_rand)
+        z_final, pd = z_in, torch.zeros((N, S1, 3), dtype=torch.float32, device=ray_batch.device)
+    ret = {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"], 'z_vals': z_final, 'position_delta': pd}
+    if retraw:
+        ret['raw'] = p1["raw"]
+    if N_importance > 0 and z_std is not None:
+        ret['z_std'] = z_std
+    return ret
+
+
+def sample_coarse_z(ray_batch, S, lindisp, t_rand):
+    from .render import sample_coarse
+    return sample_coarse(ray_batch.detach(), S, lindisp, t_rand)
+
+
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
                 z_vals=None, use_two_models_for_fine=False):
@@ -76,6 +232,11 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     plan = None
     if ray_batch.shape[-1] == 12:
         plan = fused_plan(network_query_fn, [network_fn, network_fine], need_time=True)
+        if plan is None and fused_plan(network_query_fn, [network_fn, network_fine], need_time=True, allow_train=True) is not None:
+            ret = _render_rays_train_fused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb, N_importance,
+                                           network_fine, white_bkgd, raw_noise_std, pytest, z_vals, use_two_models_for_fine)
+            if ret is not None:
+                return ret
     if plan is None:
         return _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb,
                                     N_importance, network_fine, white_bkgd, raw_noise_std, pytest, z_vals,

@@ -332,6 +332,61 @@ def test_dnerf_training_step_with_tv_loss(dev):
     assert float((after - e["rgb_map"].detach()).abs().max()) > 1e-6
 
 
+def test_fused_dnerf_training_pass_matches_op_path(dev, monkeypatch):
+    """The fused D-NeRF training pass (swnerf_render_pass_train_dnerf / _backward_dnerf: deformation net -> x+dx ->
+    canonical net -> compositing, and back, one ring over both transposed streams) against the differentiable op path
+    on the same inputs: outputs, position_delta and every parameter gradient of `_occ`, `_time`, `_time_out`; with
+    gradients on the image, on position_delta (TV term on shared depths) and on the returned raw; ragged S, several
+    backward chunks; and t == 0 (zero_canonical: the static fused pass on `_occ`, position_delta = 0)."""
+    import swnerf.embedder as embedder, swnerf.render_dnerf as rd, swnerf.render as render
+    sd_np = cases.weights_dnerf()
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = embedder.get_embedder(4, 3, 0)
+    embedtime_fn, _ = embedder.get_embedder(10, 1, 0)
+    q = lambda inputs, viewdirs, ts, network_fn: rd.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn, netchunk=1024 * 64)
+    rng = np.random.default_rng(8)
+    for n, S, Ni, tv in ((40, 64, 128, 0.5), (21, 40, 0, 0.25), (12, 64, 128, 0.0)):
+        g = cases.g8_inputs(n=n)
+        rb = lambda t: O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6., frame_time=t).to(dev)
+        tgt = T(rng.uniform(0, 1, (n, 3)).astype(np.float32)).to(dev)
+        wr = T(rng.standard_normal((n, S + Ni, 4)).astype(np.float32)).to(dev) * 1e-3
+        monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", 4096 if n != 40 else 393216)
+
+        def run(op_path):
+            if op_path:
+                monkeypatch.setenv("SWNERF_TRAIN_OP_PATH", "1")
+            else:
+                monkeypatch.delenv("SWNERF_TRAIN_OP_PATH", raising=False)
+            net = _dnerf_net(dev, sd_np)
+            e1 = rd.render_rays(rb(tv), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, perturb=0., raw_noise_std=0.)
+            e0 = rd.render_rays(rb(tv + 0.03), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, z_vals=e1["z_vals"].detach())
+            loss = torch.mean((e1["rgb_map"] - tgt) ** 2) + 0.1 * (e1["position_delta"] - e0["position_delta"]).pow(2).sum() / n \
+                + (e1["raw"] * wr).sum() + 0.05 * e1["acc_map"].mean()
+            loss.backward()
+            return e1, e0, {k: p.grad for k, p in net.named_parameters()}
+
+        f1, f0, g_f = run(False)
+        o1, o0, g_o = run(True)
+        assert list(f1.keys()) == list(o1.keys()) and list(f0.keys()) == list(o0.keys())
+        for k in f1:
+            relclose(f1[k].nan_to_num(7.0), o1[k].nan_to_num(7.0), rtol=2e-6, atol=5e-7, what=f"fused vs op path {k} (t={tv})")
+        relclose(f0["position_delta"], o0["position_delta"], rtol=2e-6, atol=5e-7, what="position_delta at the second time")
+        if tv == 0.0:
+            assert float(f1["position_delta"].abs().max()) == 0.0
+        worst = 0.0
+        for k in g_o:
+            if g_o[k] is None:
+                assert g_f[k] is None or float(g_f[k].abs().max()) == 0.0, k
+                continue
+            r = g_o[k].double().cpu().numpy()
+            d = np.abs(g_f[k].double().cpu().numpy() - r).max()
+            scale = max(np.abs(r).max(), 1e-12)
+            worst = max(worst, d / scale)
+            assert d <= 5e-6 * scale, f"t={tv} {k}: fused vs op path {d:.3e} of {scale:.3e}"
+        print(f"\n[parity] fused D-NeRF training pass vs op path, N={n} S={S}+{Ni} t={tv}: worst parameter-gradient difference {worst:.2e} of its max")
+
+
 @pytest.mark.parametrize("M", [4096, 5003, 131072 + 17])
 def test_gemm_tn_256x256_dma_path(dev, M):
     """The 256x256 weight-gradient GEMM (LDS-DMA double-buffered kernel, taken for M >= 4096) against torch in float64:
