@@ -129,7 +129,9 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         g = _zero_grads(params)                                   # 24 `_occ` tensors then 18 `_time` / `_time_out`
         slot_bufs, rgb4, dbufs = _slot_buffers(rb.device), _rgb4_buffers(rb.device), _deform_slot_buffers(rb.device)
         rows_per_ray = act.shape[0] // N
-        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // 2 // rows_per_ray) // 4 * 4)     # two gradient buffers alive per chunk
+        # two gradient buffers per chunk; 786 432 rows (= a 4096-ray fine pass in ONE chunk: 15 GB) - every extra chunk costs
+        # one atomic epilogue for each of the 20 GEMMs, and the op path this replaces held the whole pass anyway
+        chunk = max(4, (2 * _r.TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
         packed_bwd = net.packed_bwd(_lib.BWD_DNERF_FUSED)
         mask_per_ray = bits.numel() // N
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
