@@ -245,6 +245,31 @@ def extra_configs(dev):
         m.eval()
         for p in m.parameters():
             p.grad = None
+    del opt
+    # D-NeRF training step (d_nerf/run_dnerf.py:686-735, the shipped one-model configuration): the coarse pass runs under
+    # no_grad and only feeds the resampling, the fine pass trains deformation + canonical net; image loss.  FLOPs:
+    # coarse forward (64 rows) + 3 x fine (192 rows), each row through both nets
+    dn = s5["kw"]["network_fn"]
+    dn.train()
+    o, d = synth.pick_rays(400, 400, s5["K"], s5["c2w"], N_RAND, 5)
+    rd = (T(o), T(d))
+    opt_d = torch.optim.Adam(dn.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    kwd = dict(s5["kw"], perturb=1.)
+    focal = float(s5["K"][0][0])
+
+    def train_step_dnerf():
+        rgb, disp, acc, extras = render_dnerf.render(400, 400, focal, chunk=1024 * 32, rays=rd, frame_time=0.5, retraw=True, **kwd)
+        loss = torch.mean((rgb - target) ** 2)
+        opt_d.zero_grad()
+        loss.backward()
+        opt_d.step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    timeit("D-NeRF training step: 4096 rays x (64+128), one DirectTemporalNeRF at t=0.5, mse(rgb), backward, Adam", train_step_dnerf,
+           N_RAND, (N_SAMPLES + 3 * (N_SAMPLES + N_IMPORTANCE)) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM), 4, grad=True)
+    rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    dn.eval()
+    for p in dn.parameters():
+        p.grad = None
     return rows
 
 
