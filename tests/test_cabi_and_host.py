@@ -63,7 +63,8 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     assert L.swnerf_pack_net(0, None, 10, 4, 0, None, None) == -1
     # training entry points: stream sizes per kind, bit-mask buffer size, NULL / bad-kind rejection
     bwd = (2192 + 16) * 256 + 8 * 32
-    assert [L.swnerf_packed_bwd_floats_kind(k) for k in (0, 1, 2, 3)] == [bwd, bwd + 128 * 256, (1792 + 16) * 256 + 24 * 32, 0]
+    assert [L.swnerf_packed_bwd_floats_kind(k) for k in (0, 1, 2, 3, 4)] == [
+        bwd, bwd + 128 * 256, (1792 + 16) * 256 + 24 * 32, (2192 + 128 + 1792 + 16) * 256 + 32 * 32, 0]     # 3: the fused D-NeRF stream
     assert L.swnerf_packed_bwd_floats() == bwd and L.swnerf_act_floats_per_row() == 2432
     assert [L.swnerf_mask_floats(m) for m in (0, 1, 32, 33, 786432)] == [0, 2304, 2304, 4608, 786432 // 32 * 2304]
     assert L.swnerf_pack_net_bwd_kind(5, None, 10, 4, None, None) == -1
@@ -73,6 +74,27 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     assert L.swnerf_deform_forward_train(None, None, None, 4, 10, 4, 10, None, None, None, None) == -1
     assert L.swnerf_deform_backward_dx(None, None, None, 4, None, None) == -1 and b"NULL" in L.swnerf_last_error()
     assert L.swnerf_gemm_tn(None, 4, 1, None, 4, 1, 8, None, 4, None, None) == -1
+    # round 2: the fused training passes, the generic layers
+    assert [L.swnerf_train_rows(n, s_) for n, s_ in ((4096, 192), (3, 33), (5, 64), (0, 64))] == [786432, 192, 320, 0]
+    assert L.swnerf_xs_floats_per_row() == 96
+    assert L.swnerf_render_pass_train(None, None, None, None, None) == -1 and b"NULL" in L.swnerf_last_error()
+    a = built.PassArgs()
+    a.packed, a.ray_batch, a.n_rays, a.cols, a.kind, a.n_samples = 8, 8, 4, 11, 1, 64             # (never dereferenced: rejected first)
+    assert L.swnerf_render_pass_train(a, 8, 8, 8, None) == -2 and b"static net" in L.swnerf_last_error()
+    a.kind, a.n_samples = 0, 300
+    assert L.swnerf_render_pass_train(a, 8, 8, 8, None) == -2 and b"n_samples" in L.swnerf_last_error()
+    assert L.swnerf_render_pass_train_dnerf(a, 8, 8, 8, 8, 8, 8, None) == -2 and b"DirectTemporalNeRF" in L.swnerf_last_error()
+    assert L.swnerf_render_pass_backward(None, None, None, None, None, 11, None, 4, 64, 0, None, None, None, None, None, None, None) == -1
+    assert L.swnerf_render_pass_backward(8, 8, 8, 8, 8, 11, None, 4, 300, 0, None, None, None, None, 8, 8, None) == -2
+    assert L.swnerf_render_pass_backward_dnerf(None, None, None, None, None, None, 12, None, None, None, 4, 64, 0, 10, None, None, None, None,
+                                               None, None, None, None, None) == -1
+    assert L.swnerf_unslot_grad(None, 64, 256, 0, 64, 10, 4, None, 63, 0, None) == -1
+    assert L.swnerf_unslot_grad(8, 64, 256, 64, 64, 10, 4, 8, 63, 0, None) == -1                  # slots 64..127 do not exist
+    assert L.swnerf_unslot_grad_time(8, 32, 256, 33, 10, 8, 84, 63, None) == -1
+    assert L.swnerf_linear(None, 8, 4, 8, None, None, 4, 0, None, 4, None) == -1 and b"linear" in L.swnerf_last_error()
+    assert L.swnerf_linear(None, 8, 0, 8, None, None, 4, 0, None, 4, None) == 0                    # M = 0: nothing to do
+    assert L.swnerf_gemm_nn(8, 2, 4, 8, 8, 4, 4, 8, 4, None) == -1                                # lda < K
+    assert L.swnerf_relu_mask(None, None, 5, None) == -1 and L.swnerf_relu_mask(None, None, 0, None) == 0
 
 
 def test_no_cpu_fallback(built):

@@ -25,6 +25,9 @@ int main() {
   for (int L = 0; L <= 10; ++L) { for (int a = 0; a < 16; ++a) for (int h = 0; h < 2; ++h) printf("%d ", sw_time_col(a, h, L)); printf("\n"); }
   for (int h = 0; h < 2; ++h) { for (int r = 0; r < 16; ++r) printf("%d ", sw_frow(r, h)); printf("\n"); }
   printf("%d %d %d %d\n", SW_CANON_STEPS, SW_DEFORM_STEPS, SW_CANON_FLOATS, SW_DNERF_FLOATS);
+  for (int f = 0; f < SW_XS_LD; ++f) printf("%d ", sw_xs_col(f, 10, 4)); printf("\n");
+  for (int f = 0; f < SW_XS_LD; ++f) printf("%d ", sw_xs_col(f, 6, 2)); printf("\n");
+  printf("%d %d %d\n", SW_BWD_IG_STEPS, SW_BWD_DN_STEPS, SW_XS_LD);
   return 0;
 }
 '''
@@ -59,3 +62,12 @@ def test_common_header_on_host(tmp_path):
     assert 0 <= canon * 4 * 2048 - (593408 - 256 - 384) * 32 <= 0.01 * 593408 * 32
     assert 0 <= deform * 4 * 2048 - (497152 - 768) * 32 <= 0.01 * 497152 * 32
     assert canon % 8 == 0 and deform % 8 == 0
+    # the fused training pass's slot-ordered encodings (xs): slots 0..63 cover gamma(x), 64..95 gamma(d), each reference
+    # column exactly once (what swnerf_unslot_grad relies on); the fused D-NeRF backward stream = IG stream + 7 trunk layers
+    for ln, (Lp, Ld) in zip(lines[k + 3:k + 5], ((10, 4), (6, 2))):
+        cols = [int(c) for c in ln.split()]
+        assert len(cols) == 96
+        assert sorted(c for c in cols[:64] if c >= 0) == list(range(3 * (1 + 2 * Lp)))
+        assert sorted(c for c in cols[64:] if c >= 0) == list(range(3 * (1 + 2 * Ld)))
+    ig, dn, xld = (int(x) for x in lines[k + 5].split())
+    assert dn == ig + 7 * 256 and dn % 16 == 0 and xld == 96
