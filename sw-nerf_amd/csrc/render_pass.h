@@ -169,23 +169,33 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             float* mask_tile = P.bits + tix * SW_MASK_TILE_FLOATS + lane * 4;
             float* xs_row = P.xs + prow * SW_XS_LD + 4 * h;
             f32x4 mb = {0.f, 0.f, 0.f, 0.f};
-            trunk_pass<true, true, true>(emb, lds_emb, ft, true, h, in, out, head, ws, P.act_d + prow * SW_ACT_LD + 4 * h,
-                                         P.bits_d + tix * SW_MASK_TILE_FLOATS + lane * 4, true, nullptr, P.xs_d + prow * SW_XS_LD + 4 * h);
-            const float ex = head[0], ey = head[1], ez = head[2];
-            if (live && h == 0) {
-                float* o = a.dx + (ray * S + s) * 3;
-                o[0] = ex; o[1] = ey; o[2] = ez;
-            }
-            px = px + ex; py = py + ey; pz = pz + ez;
-            pe_pos(px, py, pz, h, emb);
             f32x16 demb;
-            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+            // ONE call site for both nets (a runtime loop like the inference kernel's): two would unroll the 8-layer body
+            // twice - 4800 static MFMAs, beyond what the instruction cache holds comfortably
+#pragma nounroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool dp = pass == 0;
+                trunk_pass<true, true, true>(emb, lds_emb, ft, dp, h, in, out, head, ws,
+                                             dp ? P.act_d + prow * SW_ACT_LD + 4 * h : act_row,
+                                             dp ? P.bits_d + tix * SW_MASK_TILE_FLOATS + lane * 4 : mask_tile, dp, &mb,
+                                             dp ? P.xs_d + prow * SW_XS_LD + 4 * h : xs_row);
+                if (dp) {
+                    const float ex = head[0], ey = head[1], ez = head[2];
+                    if (live && h == 0) {
+                        float* o = a.dx + (ray * S + s) * 3;
+                        o[0] = ex; o[1] = ey; o[2] = ez;
+                    }
+                    px = px + ex; py = py + ey; pz = pz + ez;
+                    pe_pos(px, py, pz, h, emb);
+                    tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {demb[4 * g], demb[4 * g + 1], demb[4 * g + 2], demb[4 * g + 3]};
-                *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {demb[4 * g], demb[4 * g + 1], demb[4 * g + 2], demb[4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
+                    }
+                }
             }
-            trunk_pass<true, true, true>(emb, lds_emb, ft, false, h, in, out, head, ws, act_row, mask_tile, false, &mb, xs_row);
+            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
             canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if (DNERF) {
 #pragma nounroll

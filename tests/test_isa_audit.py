@@ -57,15 +57,19 @@ def test_mfma_kernels_isa(asm):
             steps = 256
         if "render_pass_backward" in name:         # the fused backward: the same chain as mlp_backward_dx<false>, per tile
             steps = 16 + 128 + 256 + 256
+            if "kernelILb1" in name:               # D-NeRF: + the gamma(x+dx) columns (2 x 64) + the deformation loop body
+                steps += 128 + 256
         # the backward chains also fetch the ReLU bit masks by LDS-DMA: one fetch before the ring is primed, one per
         # static use site after it (mlp_backward_dx: views hidden, h7, loop body; deformation: h7, loop body)
         masks = 3 if ("mlp_backward_dx" in name or "render_pass_backward" in name) else (2 if "deform_backward_dx" in name else 0)
+        if "render_pass_backward_kernelILb1" in name:
+            masks = 5                                # canonical (3 sites) + deformation (h7, loop body)
         assert stats["mfma"] == 4 * steps, (name, stats)
         # ring priming: 8 steps in the render unit, 16 in the training unit (train_kernels.hip)
         training = any(k in name for k in ("mlp_backward_dx", "deform_", "mlp_forward_kernelILb0ELb1E", "render_pass_backward",
-                                           "render_pass_kernelILb0ELb1E"))
+                                           "render_pass_kernelILb0ELb1E", "render_pass_kernelILb1ELb1E"))
         assert dma == steps + (16 if training else 8) + masks, (name, dma)
-    assert len(seen) == 12
+    assert len(seen) == 14
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)
         assert m, name

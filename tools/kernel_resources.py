@@ -16,7 +16,8 @@ import __graft_entry__ as ge
 
 DYN_LDS = {  # bytes per workgroup, from the swnerf_* launch code (csrc/*.hip)
     "render_pass_kernel<false,false>": "107,776 (+28,672 with resampling)", "render_pass_kernel<true,false>": "107,776 (+28,672 with resampling)",
-    "render_pass_kernel<false,true>": "129,152 (+28,672 with resampling)", "render_pass_backward_kernel": "142,336",
+    "render_pass_kernel<false,true>": "129,152 (+28,672 with resampling)", "render_pass_kernel<true,true>": "140,544",
+    "render_pass_backward_kernel<false>": "142,336", "render_pass_backward_kernel<true>": "145,408",
     "mlp_forward_kernel": "107,776 (ring 8) / 140,544 (ring 16, training unit)", "query_points_kernel": "107,776",
     "gemm_tn_dma_kernel": "131,072 (+16,384 B2 rider / +8,192 A2 rider)",
     "deform_forward_train_kernel": "140,544", "deform_backward_dx_kernel": "140,544", "mlp_backward_dx_kernel": "140,544",
