@@ -472,6 +472,10 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
         rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
         rgbs.append(rgb.cpu().numpy())
         disps.append(disp.cpu().numpy())
+        if gt_imgs is not None and render_factor == 0:                       # nerf/run.py:204-206: PSNR against the ground truth
+            gt = gt_imgs[i]
+            gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
+            print(-10. * np.log10(np.mean(np.square(rgbs[-1] - gt))))
         if savedir is not None:
             write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
     return np.stack(rgbs, 0), np.stack(disps, 0)
