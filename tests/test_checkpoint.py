@@ -34,6 +34,15 @@ def test_roundtrip_and_discovery(tmp_path):
     assert checkpoint.reload_latest(str(tmp_path), "exp", c, d, None, no_reload=True) == (0, None)
     assert checkpoint.reload_latest(str(tmp_path), "exp", c, d, None, ft_path=p1)[0] == 10001
     assert checkpoint.to8b(np.array([-1., 0.5, 2.])).tolist() == [0, 127, 255]
+    # saved WITHOUT an optimizer: no 'optimizer_state_dict' key, and loading it into a run that has an optimizer keeps that
+    # optimizer's fresh state (round-1 advisor finding: an empty dict was written and then fed to load_state_dict)
+    p3 = checkpoint.save_checkpoint(str(tmp_path), "exp2", 5, 6, a, b, None)
+    assert "optimizer_state_dict" not in torch.load(p3, weights_only=False)
+    opt2 = torch.optim.Adam(list(c.parameters()) + list(d.parameters()), lr=1e-3)
+    assert checkpoint.load_checkpoint(p3, c, d, opt2) == 6 and opt2.param_groups[0]["lr"] == 1e-3
+    torch.save({"global_step": 7, "network_fn_state_dict": a.state_dict(), "network_fine_state_dict": b.state_dict(),
+                "optimizer_state_dict": {}}, str(tmp_path / "legacy.tar"))
+    assert checkpoint.load_checkpoint(str(tmp_path / "legacy.tar"), c, d, opt2) == 7
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
