@@ -9,13 +9,12 @@ get_embedder encoders; otherwise it runs the reference's op sequence on the indi
 ops (embed / mlp_forward / raw2outputs / sample_pdf)."""
 import inspect
 import os
-import time
 
 import numpy as np
 import torch
 
 from . import _lib
-from .ray import get_rays, ndc_rays, sample_pdf, raw2outputs, _device_of
+from .ray import get_rays, sample_pdf, raw2outputs
 from .embedder import EmbedFn, to8b
 from .png import write_png
 from .model import vallina_NeRF, NeRFOriginal, DirectTemporalNeRF
@@ -157,7 +156,6 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, rb, z_vals, S, lindisp, t_rand, noise, white_bkgd, n_importance, u, *params):
-        from .model import _zero_grads  # noqa: F401
         kind, packed, Lp, Ld, _ = net.packed()
         L = _lib.lib()
         N, cols = rb.shape

@@ -116,7 +116,6 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
     def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
                             _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot)
-        from .render import TRAIN_BWD_CHUNK_ROWS
         from . import render as _r
         rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
