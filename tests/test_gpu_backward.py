@@ -167,7 +167,10 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
     rng = np.random.default_rng(5)
     for n, S, Ni, kw in ((48, 64, 128, dict(white_bkgd=True)),
                          (37, 40, 24, dict(white_bkgd=False, lindisp=True, perturb=1., pytest=True, raw_noise_std=1.0)),
-                         (5, 33, 0, dict(white_bkgd=True))):
+                         (5, 33, 0, dict(white_bkgd=True)),
+                         (3, 2, 0, dict(white_bkgd=False)),                      # the smallest pass the reference allows
+                         (2, 256, 0, dict(white_bkgd=True, raw_noise_std=0.5, pytest=True)),   # the largest the fused backward holds in LDS
+                         (1, 64, 128, dict(white_bkgd=True, retraw=True))):      # one ray; raw returned (nerf/run.py:685)
         g = cases.g7_inputs(n=n, seed=90 + n)
         rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.).to(dev)
         tgt = T(rng.uniform(0, 1, (n, 3)).astype(np.float32)).to(dev)
