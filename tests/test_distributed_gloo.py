@@ -59,11 +59,21 @@ def _worker(rank, world, port, q):
     grads_ok = grads_ok and all(bool(torch.all(ps[k].grad == 3.0)) for k in (0, 1)) \
         and all(ps[k].grad is not None and bool(torch.all(ps[k].grad == 4.0)) for k in (2, 3)) \
         and all(ps[k].grad is None for k in (4, 5))
+    # the dense-grid query for mesh extraction shards the same way: each rank queries its contiguous
+    # shard of the R^3 points, one all-gather returns the field; the per-point query is the CPU oracle here
+    import swnerf.mesh as mesh
+    sdm = O.to_torch_sd(synth.nerf_state_dict(*synth.NET_FINE[:1], alpha_bias=synth.NET_FINE[1]))
+    qf = lambda p, dirs_: torch.cat([torch.stack([O.query_points(sdm, p, dirs_[v:v + 1].expand(p.shape[0], 3))[:, :3] for v in range(dirs_.shape[0])], 0).mean(0),
+                                     O.query_points(sdm, p, dirs_[:1].expand(p.shape[0], 3))[:, 3:4]], -1)
+    bounds = [(-1., 1.), (-1., 2.), (-4., 2.)]
+    dens_s, col_s, _ = mesh.sample_grid(bounds, 5, None, num_views=3, batch_size=40, query=qf)              # 125 points: 63 / 62 over 2 ranks
+    dens_1, col_1, _ = mesh.sample_grid(bounds, 5, None, num_views=3, batch_size=1000, query=qf, sharded=False)
+    mesh_ok = bool(np.allclose(dens_s, dens_1, atol=1e-5) and np.allclose(col_s, col_1, atol=1e-5) and dens_s.shape == (5, 5, 5))
     # the bench's timing reduction: MAX over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        q.put((img.numpy(), render_range(0, H * W).reshape(H, W, 5).numpy(), same.numpy(), rag.numpy(), float(t), grads_ok))
+        q.put((img.numpy(), render_range(0, H * W).reshape(H, W, 5).numpy(), same.numpy(), rag.numpy(), float(t), grads_ok and mesh_ok))
     dist.barrier()
     dist.destroy_process_group()
 
