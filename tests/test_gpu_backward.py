@@ -335,6 +335,65 @@ def test_dnerf_training_step_with_tv_loss(dev):
     assert float((after - e["rgb_map"].detach()).abs().max()) > 1e-6
 
 
+def test_reference_train_call_takes_the_fused_kernels(dev, monkeypatch):
+    """The call the reference's train() makes - render(..., retraw=True, **render_kwargs_train) with perturb=1
+    (nerf/run.py:684-686, d_nerf/run_dnerf.py:686-688) - must run on the FUSED training kernels, not quietly on the op
+    path: count the C entry points that get called."""
+    import swnerf.embedder as embedder, swnerf.render as render, swnerf.render_dnerf as rd
+    from swnerf import _lib
+    L = _lib.lib()
+    calls = {}
+
+    class Spy:
+        def __init__(self, lib):
+            object.__setattr__(self, "_l", lib)
+
+        def __getattr__(self, name):
+            f = getattr(self._l, name)
+            if not name.startswith("swnerf_"):
+                return f
+
+            def wrapped(*a, **k):
+                calls[name] = calls.get(name, 0) + 1
+                return f(*a, **k)
+            return wrapped
+    spy = Spy(L)
+    monkeypatch.setattr(_lib, "lib", lambda: spy)
+    monkeypatch.delenv("SWNERF_TRAIN_OP_PATH", raising=False)
+    sd_c, sd_f = cases.weights_static()
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = embedder.get_embedder(4, 3, 0)
+    embedtime_fn, _ = embedder.get_embedder(10, 1, 0)
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    g = cases.g7_inputs(n=32, seed=3)
+    K, _ = cases.synth.lego_camera(400, 400)
+    rays = (T(g["rays_o"]).to(dev), T(g["rays_d"]).to(dev))
+    nc, nf = _static_net(dev, sd_c), _static_net(dev, sd_f)
+    rgb, disp, acc, extras = render.render(400, 400, K, chunk=1024 * 32, rays=rays, retraw=True, ndc=False, near=2., far=6., use_viewdirs=True,
+                                           network_fn=nc, network_query_fn=q, N_samples=64, N_importance=128, network_fine=nf,
+                                           white_bkgd=True, perturb=1., raw_noise_std=0.)
+    assert sorted(extras.keys()) == ["acc0", "disp0", "raw", "rgb0", "z_std"] and extras["raw"].shape == (32, 192, 4)
+    (rgb.pow(2).mean() + extras["rgb0"].pow(2).mean()).backward()
+    assert calls.get("swnerf_render_pass_train") == 2 and calls.get("swnerf_render_pass_backward") == 2
+    assert not any(k in calls for k in ("swnerf_mlp_forward_train", "swnerf_mlp_backward_dx", "swnerf_embed", "swnerf_raw2outputs"))
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in list(nc.parameters()) + list(nf.parameters()))
+    # D-NeRF, the shipped one-model configuration
+    calls.clear()
+    qd = lambda inputs, viewdirs, ts, network_fn: rd.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn,
+                                                                 embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn, netchunk=1024 * 64)
+    dn = _dnerf_net(dev, cases.weights_dnerf())
+    rgb, disp, acc, extras = rd.render(400, 400, float(K[0][0]), chunk=1024 * 32, rays=rays, frame_time=0.5, retraw=True, ndc=False, near=2.,
+                                       far=6., use_viewdirs=True, network_fn=dn, network_query_fn=qd, N_samples=64, N_importance=128,
+                                       network_fine=None, white_bkgd=True, perturb=1., raw_noise_std=0., use_two_models_for_fine=False)
+    assert extras["position_delta"].shape == (32, 192, 3) and extras["position_delta"].requires_grad
+    (rgb.pow(2).mean() + extras["position_delta"].pow(2).sum()).backward()
+    assert calls.get("swnerf_render_pass") == 1                       # the no_grad coarse pass that feeds the resampling
+    assert calls.get("swnerf_render_pass_train_dnerf") == 1 and calls.get("swnerf_render_pass_backward_dnerf") == 1
+    assert not any(k in calls for k in ("swnerf_deform_forward_train", "swnerf_mlp_forward_train", "swnerf_embed", "swnerf_raw2outputs"))
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in dn.parameters())
+
+
 def test_fused_dnerf_training_pass_matches_op_path(dev, monkeypatch):
     """The fused D-NeRF training pass (swnerf_render_pass_train_dnerf / _backward_dnerf: deformation net -> x+dx ->
     canonical net -> compositing, and back, one ring over both transposed streams) against the differentiable op path
