@@ -170,7 +170,8 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
                          (5, 33, 0, dict(white_bkgd=True)),
                          (3, 2, 0, dict(white_bkgd=False)),                      # the smallest pass the reference allows
                          (2, 256, 0, dict(white_bkgd=True, raw_noise_std=0.5, pytest=True)),   # the largest the fused backward holds in LDS
-                         (1, 64, 128, dict(white_bkgd=True, retraw=True))):      # one ray; raw returned (nerf/run.py:685)
+                         (1, 64, 128, dict(white_bkgd=True, retraw=True)),       # one ray; raw returned (nerf/run.py:685)
+                         (9, 64, 64, dict(white_bkgd=True, one_net=True))):      # network_fine=None: ONE net for both passes (nerf/run.py:402)
         g = cases.g7_inputs(n=n, seed=90 + n)
         rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.).to(dev)
         tgt = T(rng.uniform(0, 1, (n, 3)).astype(np.float32)).to(dev)
@@ -185,7 +186,8 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
             else:
                 monkeypatch.delenv("SWNERF_TRAIN_OP_PATH", raising=False)
             nc, nf = _static_net(dev, sd_c), _static_net(dev, sd_f)
-            ret = render.render_rays(rb, nc, q, S, N_importance=Ni, network_fine=nf if Ni else None, **kw)
+            kw2 = {k: v for k, v in kw.items() if k != "one_net"}
+            ret = render.render_rays(rb, nc, q, S, N_importance=Ni, network_fine=nf if (Ni and not kw.get("one_net")) else None, **kw2)
             ok = ~torch.isnan(ret["disp_map"])
             # the reference's loss (nerf/run.py:688-697) plus terms that put gradients on disp_map and acc_map too
             loss = torch.mean((ret["rgb_map"] - tgt) ** 2) + 0.01 * (torch.where(ok, ret["disp_map"], torch.zeros_like(wd)) * wd).mean() \
@@ -193,7 +195,8 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
             if Ni:
                 loss = loss + torch.mean((ret["rgb0"] - tgt) ** 2)
             loss.backward()
-            return ret, {("c." + k): p.grad for k, p in nc.named_parameters()} | ({("f." + k): p.grad for k, p in nf.named_parameters()} if Ni else {})
+            return ret, {("c." + k): p.grad for k, p in nc.named_parameters()} | (
+                {("f." + k): p.grad for k, p in nf.named_parameters()} if (Ni and not kw.get("one_net")) else {})
 
         ret_f, g_f = run(False)
         ret_o, g_o = run(True)
