@@ -175,17 +175,19 @@ def _render_pass_train_dnerf(ray_batch, net, n_samples, *, z_vals=None, lindisp=
 def _render_rays_train_fused(ray_batch, network_fn, network_query_fn, N_samples, retraw, lindisp, perturb, N_importance,
                              network_fine, white_bkgd, raw_noise_std, pytest, z_vals, use_two_models_for_fine):
     """render_rays under autograd on the fused kernels, or None when this case is not covered (-> the op path).
-    Covered: ONE model for both passes (the shipped D-NeRF configs: use_two_models_for_fine False, so the coarse pass
-    only feeds the resampling and runs under no_grad, run_dnerf.py:417-421), N_importance = 0, or external z_vals; a
-    DirectTemporalNeRF at t != 0 -> the fused D-NeRF training pass, at t == 0 with zero_canonical (model.py:143-145) or a
-    NeRFOriginal -> the static fused training pass on the canonical net, position_delta = 0."""
+    A DirectTemporalNeRF at t != 0 runs the fused D-NeRF training pass; at t == 0 with zero_canonical
+    (model.py:143-145), or a NeRFOriginal, the static fused training pass on the canonical net with position_delta = 0.
+    The resampling always comes from a no_grad inference pass of the coarse net: that is what the reference does in the
+    shipped one-model configuration (run_dnerf.py:417-421), and with use_two_models_for_fine the coarse net's OWN
+    training pass (for rgb0 / position_delta_0, run_dnerf.py:410-416) runs next to it on the same depths - one extra
+    64-sample inference pass instead of a training kernel that would have to hold the resampling scratch as well."""
     from .render import render_pass_train, TRAIN_FUSED_MAX_SAMPLES, wants_grad
     from .model import NeRFOriginal
     run_fn = network_fn if network_fine is None else network_fine
     N = ray_batch.shape[0]
+    nets = [network_fn, run_fn]
     if (os.environ.get("SWNERF_TRAIN_OP_PATH") == "1" or N == 0 or ray_batch.shape[-1] != 12
-            or (N_importance > 0 and z_vals is None and use_two_models_for_fine)
-            or not isinstance(run_fn, (DirectTemporalNeRF, NeRFOriginal)) or not wants_grad([run_fn])):
+            or not all(isinstance(n_, (DirectTemporalNeRF, NeRFOriginal)) for n_ in nets) or not wants_grad(nets)):
         return None
     S1 = (z_vals.shape[-1] if z_vals is not None else N_samples + max(0, N_importance))
     if S1 > TRAIN_FUSED_MAX_SAMPLES or N_samples > TRAIN_FUSED_MAX_SAMPLES:
@@ -193,31 +195,41 @@ def _render_rays_train_fused(ray_batch, network_fn, network_query_fn, N_samples,
     t0 = _single_time(ray_batch)
     deform = lambda net: isinstance(net, DirectTemporalNeRF) and not (t0 == 0. and net.zero_canonical)
     t_rand, u, noise = _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
-    z_std = None
+
+    def train_pass(net, S, z_in, tr, nz):
+        """-> (dict with rgb_map disp_map acc_map raw, depths, position_delta) of one differentiable pass of `net`"""
+        if deform(net):
+            p = _render_pass_train_dnerf(ray_batch, net, S, z_vals=z_in, lindisp=lindisp, t_rand=tr, noise=nz, white_bkgd=white_bkgd)
+            return p, p["z"], p["dx"]
+        canon = net._occ if isinstance(net, DirectTemporalNeRF) else net
+        p = render_pass_train(ray_batch, canon, S, z_vals=z_in, lindisp=lindisp, t_rand=tr, noise=nz, white_bkgd=white_bkgd)
+        if z_in is None:
+            with torch.no_grad():
+                z_in = sample_coarse_z(ray_batch, S, lindisp, tr)
+        return p, z_in, torch.zeros((N, S, 3), dtype=torch.float32, device=ray_batch.device)
+
+    z_std = p0t = pd0 = None
     if z_vals is None and N_importance > 0:
-        with torch.no_grad():                                    # the resampling pass: inference kernel (run_dnerf.py:417-421)
-            p0 = render_pass(ray_batch.detach(), network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
+        nz0 = noise(N_samples)                                   # ONE draw for the coarse evaluation, whichever kernels run it
+        with torch.no_grad():                                    # the resampling: inference kernel on the coarse net
+            p0 = render_pass(ray_batch.detach(), network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=nz0,
                              white_bkgd=white_bkgd, want=[], n_importance=N_importance, u=u, run_deform=deform(network_fn))
+        if use_two_models_for_fine:                              # ... and the coarse net's own differentiable outputs
+            p0t, _, pd0 = train_pass(network_fn, N_samples, None, t_rand, nz0)
         z_in, z_std, t_rand = p0["z_fine"], p0["z_std"], None
     else:
         z_in = None if z_vals is None else _lib.dev_f32(z_vals, "z_vals")
         if z_in is not None:
             t_rand = None
-    if deform(run_fn):
-        p1 = _render_pass_train_dnerf(ray_batch, run_fn, S1, z_vals=z_in, lindisp=lindisp, t_rand=t_rand, noise=noise(S1), white_bkgd=white_bkgd)
-        z_final, pd = p1["z"], p1["dx"]
-    else:
-        canon = run_fn._occ if isinstance(run_fn, DirectTemporalNeRF) else run_fn
-        p1 = render_pass_train(ray_batch, canon, S1, z_vals=z_in, lindisp=lindisp, t_rand=t_rand, noise=noise(S1), white_bkgd=white_bkgd)
-        if z_in is None:
-            with torch.no_grad():
-                z_in = sample_coarse_z(ray_batch, S1, lindisp, t_rand)
-        z_final, pd = z_in, torch.zeros((N, S1, 3), dtype=torch.float32, device=ray_batch.device)
+    p1, z_final, pd = train_pass(run_fn, S1, z_in, t_rand, noise(S1))
     ret = {'rgb_map': p1["rgb_map"], 'disp_map': p1["disp_map"], 'acc_map': p1["acc_map"], 'z_vals': z_final, 'position_delta': pd}
     if retraw:
         ret['raw'] = p1["raw"]
-    if N_importance > 0 and z_std is not None:
-        ret['z_std'] = z_std
+    if N_importance > 0:
+        if p0t is not None:
+            ret['rgb0'], ret['disp0'], ret['acc0'], ret['position_delta_0'] = p0t["rgb_map"], p0t["disp_map"], p0t["acc_map"], pd0
+        if z_std is not None:
+            ret['z_std'] = z_std
     return ret
 
 

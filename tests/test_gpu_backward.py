@@ -411,12 +411,14 @@ def test_fused_dnerf_training_pass_matches_op_path(dev, monkeypatch):
     q = lambda inputs, viewdirs, ts, network_fn: rd.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn,
                                                                 embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn, netchunk=1024 * 64)
     rng = np.random.default_rng(8)
-    for n, S, Ni, tv in ((40, 64, 128, 0.5), (21, 40, 0, 0.25), (12, 64, 128, 0.0)):
+    for n, S, Ni, tv in ((40, 64, 128, 0.5), (21, 40, 0, 0.25), (12, 64, 128, 0.0), (10, 64, 64, -0.5)):     # tv < 0: two models, t = |tv|
         g = cases.g8_inputs(n=n)
         rb = lambda t: O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6., frame_time=t).to(dev)
         tgt = T(rng.uniform(0, 1, (n, 3)).astype(np.float32)).to(dev)
         wr = T(rng.standard_normal((n, S + Ni, 4)).astype(np.float32)).to(dev) * 1e-3
         monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", 4096 if n != 40 else 393216)
+
+        two, tv = tv < 0, abs(tv)
 
         def run(op_path):
             if op_path:
@@ -424,12 +426,19 @@ def test_fused_dnerf_training_pass_matches_op_path(dev, monkeypatch):
             else:
                 monkeypatch.delenv("SWNERF_TRAIN_OP_PATH", raising=False)
             net = _dnerf_net(dev, sd_np)
-            e1 = rd.render_rays(rb(tv), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, perturb=0., raw_noise_std=0.)
-            e0 = rd.render_rays(rb(tv + 0.03), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, z_vals=e1["z_vals"].detach())
+            fine = _dnerf_net(dev, sd_np) if two else None            # use_two_models_for_fine (run_dnerf.py:410-416)
+            kw2 = dict(network_fine=fine, use_two_models_for_fine=two)
+            e1 = rd.render_rays(rb(tv), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, perturb=0., raw_noise_std=0., **kw2)
+            e0 = rd.render_rays(rb(tv + 0.03), net, q, S, N_importance=Ni, retraw=True, white_bkgd=True, z_vals=e1["z_vals"].detach(), **kw2)
             loss = torch.mean((e1["rgb_map"] - tgt) ** 2) + 0.1 * (e1["position_delta"] - e0["position_delta"]).pow(2).sum() / n \
                 + (e1["raw"] * wr).sum() + 0.05 * e1["acc_map"].mean()
+            if two:
+                loss = loss + torch.mean((e1["rgb0"] - tgt) ** 2) + 0.1 * e1["position_delta_0"].pow(2).sum() / n
             loss.backward()
-            return e1, e0, {k: p.grad for k, p in net.named_parameters()}
+            g_ = {k: p.grad for k, p in net.named_parameters()}
+            if two:
+                g_.update({"fine." + k: p.grad for k, p in fine.named_parameters()})
+            return e1, e0, g_
 
         f1, f0, g_f = run(False)
         o1, o0, g_o = run(True)
