@@ -83,6 +83,21 @@ __device__ __forceinline__ float z_sample(const swnerf_pass_args& a, int64_t ray
     return lower + (upper - lower) * a.t_rand[ray * S + s];
 }
 
+// -DSW_PROBE builds (tools/probe_segments.py; never the shipped library): shader-clock stamps around the parts of a
+// tile, accumulated per wave in SGPRs and written, as raw 64-bit counters, into the ray's `weights` row.
+#ifdef SW_PROBE
+__device__ __forceinline__ unsigned long long sw_clock() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SW_STAMP(var) const unsigned long long var = sw_clock()
+#else
+#define SW_STAMP(var)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // TRAIN, static net: the LDS bias region holds the canonical tiles alone (the deformation tiles' 11 KB are what lets the
 // 16-deep ring of the training translation unit AND the resampling scratch fit into 160 KB).  TRAIN + DNERF keeps both
@@ -96,6 +111,7 @@ template <bool DNERF, bool TRAIN> struct PassLds {
 template <bool DNERF, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    SW_STAMP(probe_start);
     const swnerf_pass_args& a = P.a;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -134,8 +150,13 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
     double Tc = 1.0;                              // transmittance carried across tiles
     const int ntiles = (S + 31) >> 5;
+#ifdef SW_PROBE
+    unsigned long long probe_acc[4] = {0ull, 0ull, 0ull, 0ull};
+    SW_STAMP(probe_loop0);
+#endif
 #pragma nounroll
     for (int tile = 0; tile < ntiles; ++tile) {
+        SW_STAMP(pt0);
         const int s = tile * 32 + j;
         const bool live = s < S;
         const int sc = live ? s : S - 1;
@@ -160,6 +181,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         f32x16 emb[2], in[8], out[8];
         float head[3], rgb[3];
         pe_pos(px, py, pz, h, emb);
+        SW_STAMP(pt1);
         if (DNERF && TRAIN) {
             // deformation net, then the canonical net on gamma(x + dx) (model.py:128-151); both save what their dX
             // chains and weight-gradient GEMMs need, as side stores (see the static branch below).  Always both passes:
@@ -236,11 +258,13 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         } else {
             trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
         }
+        SW_STAMP(pt2);
         if (!TRAIN) {
             f32x16 demb;
             tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
             canon_tail(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
         }
+        SW_STAMP(pt3);
         ws_rewind(ws, P.w0, lds_bias, lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
@@ -276,6 +300,12 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         pb += w * (1.f / (1.f + expf(-c2)));
         pd += w * z;
         pa += w;
+#ifdef SW_PROBE
+        {
+            SW_STAMP(pt4);
+            probe_acc[0] += pt1 - pt0; probe_acc[1] += pt2 - pt1; probe_acc[2] += pt3 - pt2; probe_acc[3] += pt4 - pt3;
+        }
+#endif
     }
 
     pr = wave32_sum(pr); pg = wave32_sum(pg); pb = wave32_sum(pb);
@@ -294,6 +324,13 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             a.disp_map[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
         }
     }
+#ifdef SW_PROBE
+    if (a.weights && lane == 0) {          // [sampling+encoding, trunk, tail, compositing, whole tile loop, prologue] cycles of this wave
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.weights + ray * S);
+        const unsigned long long pend = sw_clock();
+        o[0] = probe_acc[0]; o[1] = probe_acc[1]; o[2] = probe_acc[2]; o[3] = probe_acc[3]; o[4] = pend - probe_loop0; o[5] = probe_loop0 - probe_start;
+    }
+#endif
     if (!resample) return;
 
     // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; then sort (nerf/run.py:396-400)
