@@ -43,3 +43,65 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "{" not in r.stdout and "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_c_abi_from_plain_cpp_matches_python_mirror(tmp_path):
+    """examples/cabi_demo.cpp drives libswnerf_hip.so with hipMalloc'd buffers only (no Python, no torch): get_rays ->
+    pack_ray_batch -> coarse pass + resampling -> fine pass.  The same render through the reference-shaped Python
+    surface (render.render with the create_nerf kwargs) on the weights the demo dumped must agree BIT FOR BIT: both
+    are the same kernels behind the same C ABI, the Python side adds nothing to the arithmetic."""
+    import numpy as np
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: starting programs from it is not allowed on this pool")
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.compile_library()
+    libdir = os.path.join(ROOT, "sw-nerf_amd", "swnerf")
+    exe, dump = str(tmp_path / "cabi_demo"), str(tmp_path / "dump.bin")
+    c = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "cabi_demo.cpp"), "-L", libdir, "-lswnerf_hip", f"-Wl,-rpath,{libdir}", "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    assert c.returncode == 0, c.stderr[-3000:]
+    r = subprocess.run([exe, dump], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "cabi_demo: 256 rays" in r.stdout
+
+    sys.path.insert(0, os.path.join(ROOT, "sw-nerf_amd"))
+    import swnerf.embedder, swnerf.model, swnerf.render   # noqa
+    import swnerf as sw
+    blob = np.fromfile(dump, dtype=np.float32)
+    names = list(sw.model.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True).state_dict().keys())
+    dev, pos, nets = torch.device("cuda:0"), 0, []
+    for _ in range(2):
+        m = sw.model.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        sd = {}
+        for k in names:
+            n = m.state_dict()[k].numel()
+            sd[k] = torch.from_numpy(blob[pos:pos + n].copy()).reshape(m.state_dict()[k].shape)
+            pos += n
+        m.load_state_dict(sd)
+        nets.append(m.to(dev).eval())
+    N = 256
+    rgb0, rgb, acc = (blob[pos:pos + 3 * N].reshape(16, 16, 3), blob[pos + 3 * N:pos + 6 * N].reshape(16, 16, 3),
+                      blob[pos + 6 * N:pos + 7 * N].reshape(16, 16))
+    assert pos + 7 * N == blob.size
+    embed_fn, _ = sw.embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = sw.embedder.get_embedder(4, 3, 0)
+    query = lambda inputs, viewdirs, network_fn: sw.render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,  # noqa: E731
+                                                                       embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    import math
+    focal = 0.5 * 16 / math.tan(0.5 * 0.6911112070083618)
+    K = np.array([[focal, 0, 8.0], [0, focal, 8.0], [0, 0, 1]])
+    c2w = torch.tensor([[1., 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4]], device=dev)
+    with torch.no_grad():
+        out = sw.render.render(16, 16, K, chunk=1024 * 32, c2w=c2w, ndc=False, near=2., far=6., use_viewdirs=True, network_fn=nets[0],
+                               network_query_fn=query, N_samples=64, N_importance=128, network_fine=nets[1], white_bkgd=True,
+                               perturb=0., raw_noise_std=0.)
+    assert np.array_equal(out[0].cpu().numpy(), rgb), np.abs(out[0].cpu().numpy() - rgb).max()
+    assert np.array_equal(out[2].cpu().numpy(), acc)
+    assert np.array_equal(out[3]["rgb0"].cpu().numpy(), rgb0)
+    # a fog of varying density: every ray is absorbed by the far plane's 1e10-wide last bin (acc == 1 up to rounding) but the
+    # colour is set along the way and differs between pixels and between the coarse and the fine net
+    assert acc.min() > 0.99 and rgb.std() > 1e-3 and 0.05 < rgb.mean() < 0.95 and np.abs(rgb - rgb0).max() > 1e-3, (rgb.mean(), rgb.std())
