@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 102
+#define SWNERF_VERSION 103
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -232,6 +232,19 @@ typedef struct swnerf_pass_args {
 } swnerf_pass_args;
 
 int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);
+
+/* ---- opt-in reduced-cost precision: "bf16x3" ----------------------------------------------------------------
+ * swnerf_render_pass with the MLP on the bf16 matrix pipe: every fp32 weight and activation is split into two bf16
+ * halves (hi + lo, 16 significant bits) and each product is three v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (W_hi.x_hi + W_hi.x_lo + W_lo.x_hi).  Sampling, encodings, heads, compositing and resampling stay fp32 and are the
+ * same code as swnerf_render_pass.  NOT the parity path (that is fp32 MFMA, bit-comparable to torch's CPU kernels up to
+ * summation order); measured deviation from it: DESIGN.md.  Static canonical net only (SWNERF_NET_CANON);
+ * args->packed = a blob from swnerf_pack_net_x3 (swnerf_packed_x3_floats() floats), built from the same 24 tensors
+ * plus the fp32 blob of swnerf_pack_net (its bias tiles are copied).  terms: 3 = bf16x3, 1 = plain bf16 (hi only). */
+size_t swnerf_packed_x3_floats(void);
+int swnerf_pack_net_x3(const float* const* params /*HOST*/, int L_pos, int L_dir, const float* packed_canon,
+                       float* packed_x3, void* stream);
+int swnerf_render_pass_x3(const swnerf_pass_args* args /*HOST*/, int terms, void* stream);
 
 /* ---- the fused pass under autograd: loss.backward() of the reference's training step --------------------------
  * (nerf/run.py:684-708: render -> img2mse(rgb) + img2mse(rgb0) -> backward -> optimizer.step)

@@ -27,6 +27,21 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// -DSW_PROBE builds (tools/probe_segments.py; never the shipped library): shader-clock stamps around the parts of a
+// tile, accumulated per wave in SGPRs and written, as raw 64-bit counters, into the ray's `weights` row.
+#ifdef SW_PROBE
+__device__ __forceinline__ unsigned long long sw_clock() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define SW_STAMP(var) const unsigned long long var = sw_clock()
+#else
+#define SW_STAMP(var)
+#endif
+
 // The weight ring lives in LDS and is filled by LDS-DMA (`global_load_lds_dwordx4`: global ->
 // LDS with no VGPR destination): each wave owns SW_RING slots of 1 KiB and keeps SW_RING-1
 // steps in flight.  Why not a register ring: hipcc (ROCm 7.2) sinks plain prefetch loads next

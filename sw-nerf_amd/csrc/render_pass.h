@@ -11,6 +11,7 @@
 // sample_pdf ray.py:96-153; run_network nerf/run.py:73-87.
 #pragma once
 #include "mlp_kernels.h"
+#include "mlp_core_x3.h"
 
 #define SW_LDS_SC 256                    // max coarse samples when resampling
 #define SW_LDS_SORT 1024                 // max S + n_importance (padded to a power of two)
@@ -83,21 +84,6 @@ __device__ __forceinline__ float z_sample(const swnerf_pass_args& a, int64_t ray
     return lower + (upper - lower) * a.t_rand[ray * S + s];
 }
 
-// -DSW_PROBE builds (tools/probe_segments.py; never the shipped library): shader-clock stamps around the parts of a
-// tile, accumulated per wave in SGPRs and written, as raw 64-bit counters, into the ray's `weights` row.
-#ifdef SW_PROBE
-__device__ __forceinline__ unsigned long long sw_clock() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define SW_STAMP(var) const unsigned long long var = sw_clock()
-#else
-#define SW_STAMP(var)
-#endif
-
 // ------------------------------------------------------------------------------------------
 // TRAIN, static net: the LDS bias region holds the canonical tiles alone (the deformation tiles' 11 KB are what lets the
 // 16-deep ring of the training translation unit AND the resampling scratch fit into 160 KB).  TRAIN + DNERF keeps both
@@ -107,21 +93,35 @@ template <bool DNERF, bool TRAIN> struct PassLds {
     static constexpr int BIAS = (TRAIN && !DNERF) ? SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS : SW_LDS_BIAS_FLOATS;
     static constexpr int FIXED = BIAS + 4 * SW_LDS_RING_FLOATS;
 };
+// PREC != 0 (bf16x3 / bf16 pass, mlp_core_x3.h): bias tiles | the workgroup's shared weight ring | per wave: gamma(d)
+// tile + depth slots | per wave: resampling scratch
+#define X3_WAVE_FLOATS (16 * 64 + SW_ZSLOT_FLOATS)
+#define X3_LDS_FIXED_FLOATS (SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS + X3_RING_FLOATS + 4 * X3_WAVE_FLOATS)
 
-template <bool DNERF, bool TRAIN = false>
+// PREC: 0 = fp32 MFMA (mlp_core.h, the parity path); 3 = bf16x3, 1 = plain bf16 (mlp_core_x3.h; static net, inference)
+template <bool DNERF, bool TRAIN = false, int PREC = 0>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
+    static_assert(PREC == 0 || (!DNERF && !TRAIN), "the bf16 paths cover the static inference pass");
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     SW_STAMP(probe_start);
     const swnerf_pass_args& a = P.a;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_all, P.b0, P.nbias);         // the only block barrier; waves are independent after it
-    if (ray >= a.n_rays) return;                 // wave-uniform
+    const int64_t ray_id = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_all, P.b0, P.nbias);         // fp32 path: the only block barrier; waves are independent after it
+    // PREC: the four waves share the weight ring and run in step, so a wave past the last ray follows along on the
+    // last ray and stores nothing
+    const bool ghost = PREC != 0 && ray_id >= a.n_rays;
+    if (PREC == 0 && ray_id >= a.n_rays) return; // wave-uniform
+    const int64_t ray = ghost ? a.n_rays - 1 : ray_id;
     const float* lds_bias = lds_all;
-    float* lds_ring = lds_all + PassLds<DNERF, TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS;
+    float* lds_ring = PREC ? lds_all + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS
+                           : lds_all + PassLds<DNERF, TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS;
     float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    float* lds = lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
+    float* lds_x3w = lds_ring + X3_RING_FLOATS + wv * X3_WAVE_FLOATS;
+    float* lds_dir = PREC ? lds_x3w : lds_emb + 2 * 16 * 64;
+    float* lds = PREC ? lds_all + X3_LDS_FIXED_FLOATS + wv * SW_LDS_WAVE_FLOATS
+                      : lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
     float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
     float* cdf = lds + 2 * SW_LDS_SC;            // [S-1]
@@ -139,13 +139,15 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     {   // once per ray: the view-direction encoding, parked in LDS (see tile_park)
         f32x16 demb;
         pe_dir(v0, v1, v2, h, demb);
-        tile_park(lds_emb + 2 * 16 * 64, lane, demb);
+        tile_park(lds_dir, lane, demb);
     }
     WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    XStream xs;
+    if constexpr (PREC != 0) x3_start(xs, reinterpret_cast<const char*>(P.w0), lds_bias, lds_ring, lane, wv);
+    else ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
     const float* zrow = a.z_vals ? a.z_vals + ray * S : nullptr;
-    const float* zslot = lds_emb + SW_EMB_LDS_FLOATS;
+    const float* zslot = PREC ? lds_x3w + 16 * 64 : lds_emb + SW_EMB_LDS_FLOATS;
     const unsigned zslot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)zslot);
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
     double Tc = 1.0;                              // transmittance carried across tiles
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     for (int tile = 0; tile < ntiles; ++tile) {
         SW_STAMP(pt0);
         const int s = tile * 32 + j;
-        const bool live = s < S;
+        const bool live = s < S && !ghost;
         const int sc = live ? s : S - 1;
         float z, zn;
         if (zrow && tile > 0) {
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                     }
                     px = px + ex; py = py + ey; pz = pz + ez;
                     pe_pos(px, py, pz, h, emb);
-                    tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+                    tile_fetch(lds_dir, lane, demb);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {demb[4 * g], demb[4 * g + 1], demb[4 * g + 2], demb[4 * g + 3]};
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                     }
                 }
             }
-            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+            tile_fetch(lds_dir, lane, demb);
             canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if (DNERF) {
 #pragma nounroll
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             float* xs_row = P.xs + prow * SW_XS_LD + 4 * h;
             f32x4 mb = {0.f, 0.f, 0.f, 0.f};
             f32x16 demb;
-            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+            tile_fetch(lds_dir, lane, demb);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {                                    // gamma(d): k-tile 2 of the slot-ordered row
                 const f32x4 v = {demb[4 * g], demb[4 * g + 1], demb[4 * g + 2], demb[4 * g + 3]};
@@ -255,17 +257,21 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             }
             trunk_pass<false, true, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb, xs_row);
             canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+        } else if constexpr (PREC != 0) {
+            head[1] = 0.f; head[2] = 0.f;
+            x3_canon<PREC>(px, py, pz, h, lds_dir, lane, head[0], rgb, xs);
+            x3_rewind(xs, SW_X3_CANON_CHUNKS, lds_bias, lane);
         } else {
             trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
         }
         SW_STAMP(pt2);
-        if (!TRAIN) {
+        if (!TRAIN && PREC == 0) {
             f32x16 demb;
-            tile_fetch(lds_emb + 2 * 16 * 64, lane, demb);
+            tile_fetch(lds_dir, lane, demb);
             canon_tail(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
         }
         SW_STAMP(pt3);
-        ws_rewind(ws, P.w0, lds_bias, lane);
+        if constexpr (PREC == 0) ws_rewind(ws, P.w0, lds_bias, lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
         const float c0 = rgb[0], c1 = rgb[1], c2 = rgb[2];
@@ -310,7 +316,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
 
     pr = wave32_sum(pr); pg = wave32_sum(pg); pb = wave32_sum(pb);
     pd = wave32_sum(pd); pa = wave32_sum(pa);
-    if (lane == 0) {
+    if (lane == 0 && !ghost) {
         if (a.rgb_map) {
             const float bg = a.white_bkgd ? (1.f - pa) : 0.f;                // ray.py:195-196
             a.rgb_map[ray * 3 + 0] = pr + bg;
@@ -325,13 +331,14 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         }
     }
 #ifdef SW_PROBE
-    if (a.weights && lane == 0) {          // [sampling+encoding, trunk, tail, compositing, whole tile loop, prologue] cycles of this wave
+    if (a.weights && lane == 0 && !ghost) {          // [sampling+encoding, trunk, tail, compositing, whole tile loop, prologue] cycles of this wave
         unsigned long long* o = reinterpret_cast<unsigned long long*>(a.weights + ray * S);
         const unsigned long long pend = sw_clock();
         o[0] = probe_acc[0]; o[1] = probe_acc[1]; o[2] = probe_acc[2]; o[3] = probe_acc[3]; o[4] = pend - probe_loop0; o[5] = probe_loop0 - probe_start;
+        if constexpr (PREC != 0) { o[6] = xs.pc[0]; o[7] = xs.pc[1]; o[8] = xs.pc[2]; }
     }
 #endif
-    if (!resample) return;
+    if (!resample || ghost) return;
 
     // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; then sort (nerf/run.py:396-400)
     wave_lds_sync();

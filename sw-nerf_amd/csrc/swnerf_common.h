@@ -81,6 +81,16 @@
 #define SW_DBWD_BIAS_TILES 24
 #define SW_DBWD_FLOATS (SW_DBWD_W_FLOATS + SW_DBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
+// ---- bf16x3 path (mlp_core_x3.h): canonical net as k-block-major groups of [A_hi 1 KiB][A_lo 1 KiB], 8 groups per chunk --
+// groups: L0 8x4 | L1..L4 8x16 each | L5 8x20 (h then gamma(x)) | L6 L7 8x16 | FEAT 8x16 | VIEWS 4x18 (feature then gamma(d))
+#define SW_X3_CANON_GROUPS (32 + 4 * 128 + 160 + 2 * 128 + 128 + 72)
+#define SW_X3_CANON_CHUNKS (SW_X3_CANON_GROUPS / 8)
+#define SW_X3_TAIL_CHUNKS 8       // the stream ends with a copy of its first chunks (>= ring slots)
+#define SW_X3_CHUNK_FLOATS 4096
+#define SW_X3_W_FLOATS ((SW_X3_CANON_CHUNKS + SW_X3_TAIL_CHUNKS) * SW_X3_CHUNK_FLOATS)
+// blob: [weight stream + tail][the canonical bias tiles, as in the fp32 blob]
+#define SW_X3_FLOATS (SW_X3_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+
 // C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile
 SW_HD int sw_frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

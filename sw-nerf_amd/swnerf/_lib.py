@@ -19,7 +19,8 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
            "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
            "swnerf_render_pass_train_dnerf", "swnerf_render_pass_backward_dnerf", "swnerf_unslot_grad_time",
-           "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask"]
+           "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask",
+           "swnerf_packed_x3_floats", "swnerf_pack_net_x3", "swnerf_render_pass_x3"]
 BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM, BWD_DNERF_FUSED = 0, 1, 2, 3
 
 
@@ -107,12 +108,16 @@ def lib():
     L.swnerf_linear.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
     L.swnerf_gemm_nn.argtypes = [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
     L.swnerf_relu_mask.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+    L.swnerf_packed_x3_floats.restype = c_size_t
+    L.swnerf_packed_x3_floats.argtypes = []
+    L.swnerf_pack_net_x3.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_void_p]
+    L.swnerf_render_pass_x3.argtypes = [POINTER(PassArgs), c_int, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
                         "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 102:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 102 - rebuild it "
+    if L.swnerf_version() != 103:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 103 - rebuild it "
                            "(python __graft_entry__.py)")
     _lib = L
     return L

@@ -105,12 +105,34 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
     return ef.multires, edf.multires, Lt
 
 
+# Arithmetic of the fused INFERENCE pass of the static nets: "fp32" (fp32 MFMA: the parity path, the default and what
+# bench.py's headline measures), "bf16x3" (split-bf16 MFMA with fp32 accumulation, ~16 significant bits per operand; see
+# include/swnerf.h swnerf_render_pass_x3) or "bf16" (plain bf16 operands).  Opt-in: set_precision() or SWNERF_PRECISION.
+_PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16": 1}
+PRECISION = os.environ.get("SWNERF_PRECISION", "fp32")
+
+
+def set_precision(name):
+    """Select the arithmetic of the fused inference pass; returns the previous setting."""
+    global PRECISION
+    if name not in _PRECISIONS:
+        raise ValueError(f"swnerf.render.set_precision: unknown precision {name!r} (one of {sorted(_PRECISIONS)})")
+    prev, PRECISION = PRECISION, name
+    return prev
+
+
 def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
-                want=("rgb_map", "disp_map", "acc_map"), n_importance=0, u=None, run_deform=True):
+                want=("rgb_map", "disp_map", "acc_map"), n_importance=0, u=None, run_deform=True, precision=None):
     """One launch of `swnerf_render_pass` (include/swnerf.h).  Returns a dict of the requested
     outputs among rgb_map disp_map acc_map depth_map weights raw dx z_out, plus z_fine/z_std
-    when n_importance > 0."""
+    when n_importance > 0.  precision: None = the module setting (PRECISION); the bf16 paths exist for the static
+    canonical net, any other net runs fp32."""
     kind, packed, Lp, Ld, Lt = net.packed()
+    terms = _PRECISIONS[PRECISION if precision is None else precision]
+    if terms and kind == _lib.NET_CANON:
+        packed, _, _ = net.packed_x3()
+    else:
+        terms = 0
     rb = _lib.dev_f32(ray_batch, "ray_batch")
     N, cols = rb.shape
     S = int(n_samples)
@@ -140,7 +162,10 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
         a.z_fine, a.z_std = out["z_fine"].data_ptr(), out["z_std"].data_ptr()
     if PASS_HOOK is not None:
         PASS_HOOK("begin", N, S)
-    _lib.check(_lib.lib().swnerf_render_pass(a, _lib.stream_of(rb)), "render_pass")
+    if terms:
+        _lib.check(_lib.lib().swnerf_render_pass_x3(a, terms, _lib.stream_of(rb)), "render_pass_x3")
+    else:
+        _lib.check(_lib.lib().swnerf_render_pass(a, _lib.stream_of(rb)), "render_pass")
     if PASS_HOOK is not None:
         PASS_HOOK("end", N, S)
     return out
