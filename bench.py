@@ -211,6 +211,27 @@ def extra_configs(dev):
     rb4 = O.make_ray_batch(o8.reshape(-1, 3)[lo:lo + 512], d8.reshape(-1, 3)[lo:lo + 512], 2., 6.)
     timeit("C4 shard: rank 3 of 8 of the 800x800 frame, 80 000 rays incl. get_rays", lambda: rr4(lo, hi - lo), hi - lo, st["flop_per_ray"], 3,
            ref=lambda: O.render_rays(rb4, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+    # the opt-in bf16x3 arithmetic (csrc/mlp_core_x3.h) on the same C4 shard: NOT the headline (that is fp32) - rays/s, the
+    # PSNR against the same CPU oracle rays and against this library's fp32 render of the whole shard, and the bf16 MFMA
+    # rate it sustains (3 MFMAs per product: 3 x the algorithmic FLOPs) against the 2.5 PFLOP/s dense bf16 peak
+    with torch.no_grad():
+        ref4 = rr4(lo, hi - lo)[:, :3].clone()
+    for mode, what, share in (("bf16x3", "both passes", 1.0), ("bf16x3-fine", "fine pass only, the coarse pass that feeds the resampling stays fp32", 0.75)):
+        prev = render.set_precision(mode)
+        try:
+            timeit(f"C4 shard, {mode} arithmetic (opt-in; 3 bf16 MFMAs per product, fp32 accumulate; {what})", lambda: rr4(lo, hi - lo), hi - lo,
+                   st["flop_per_ray"], 3, ref=lambda: O.render_rays(rb4, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+            with torch.no_grad():
+                got4 = rr4(lo, hi - lo)[:, :3]
+        finally:
+            render.set_precision(prev)
+        r = rows[-1]
+        r["dtype"] = mode
+        r["psnr_vs_fp32_pass_db"] = float(-10 * torch.log10(torch.mean((got4.double() - ref4.double()) ** 2)))
+        if share == 1.0:
+            r["bf16_mfma_tflops"] = 3 * r["algorithmic_tflops"]
+            r["bf16_mfma_frac_of_2500"] = r["bf16_mfma_tflops"] / 2500.0
+        r["frac"] = None                              # the fp32-MFMA roofline does not apply to these rows
     s5 = build_scene("C5", dev, 0)
     lo5, hi5 = synth.shard_range(400 * 400, 8, 3)
     sd_d = O.to_torch_sd(s5["sds_np"][0])
@@ -221,6 +242,27 @@ def extra_configs(dev):
         timeit(f"C5 shard: D-NeRF rank 3 of 8 of the 400x400 frame, 20 000 rays, t={tv}", lambda: rr5(lo5, hi5 - lo5), hi5 - lo5,
                s5["flop_per_ray"] if tv else st["flop_per_ray"], 3,
                ref=lambda rb5=rb5: O.render_rays_dnerf(rb5, sd_d, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+    # ... and the D-NeRF shard at t = 0.5 in bf16x3 (deformation + canonical net in one pass; the fp32 row is two rows up)
+    rr5 = parallel.frame_renderer(400, 400, s5["K"], s5["c2w"], s5["kw"], frame_time=0.5, device=dev)
+    rb5 = O.make_ray_batch(o4.reshape(-1, 3)[lo5:lo5 + 256], d4.reshape(-1, 3)[lo5:lo5 + 256], 2., 6., frame_time=0.5)
+    with torch.no_grad():
+        ref5 = rr5(lo5, hi5 - lo5)[:, :3].clone()
+    for mode in ("bf16x3", "bf16x3-fine"):
+        prev = render.set_precision(mode)
+        try:
+            timeit(f"C5 shard t=0.5, {mode} arithmetic (opt-in)", lambda: rr5(lo5, hi5 - lo5), hi5 - lo5, s5["flop_per_ray"], 3,
+                   ref=lambda: O.render_rays_dnerf(rb5, sd_d, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+            with torch.no_grad():
+                got5 = rr5(lo5, hi5 - lo5)[:, :3]
+        finally:
+            render.set_precision(prev)
+        r = rows[-1]
+        r["dtype"] = mode
+        r["psnr_vs_fp32_pass_db"] = float(-10 * torch.log10(torch.mean((got5.double() - ref5.double()) ** 2)))
+        if mode == "bf16x3":
+            r["bf16_mfma_tflops"] = 3 * r["algorithmic_tflops"]
+            r["bf16_mfma_frac_of_2500"] = r["bf16_mfma_tflops"] / 2500.0
+        r["frac"] = None
     # training step of the reference (nerf/run.py:684-708): render -> img2mse -> backward -> Adam; 3x the forward FLOPs
     nets = [kw["network_fn"], kw["network_fine"]]
     for m in nets:

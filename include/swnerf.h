@@ -234,13 +234,18 @@ typedef struct swnerf_pass_args {
 int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);
 
 /* ---- opt-in reduced-cost precision: "bf16x3" ----------------------------------------------------------------
- * swnerf_render_pass with the MLP on the bf16 matrix pipe: every fp32 weight and activation is split into two bf16
+ * swnerf_render_pass with the MLPs on the bf16 matrix pipe: every fp32 weight and activation is split into two bf16
  * halves (hi + lo, 16 significant bits) and each product is three v_mfma_f32_32x32x16_bf16 with fp32 accumulation
  * (W_hi.x_hi + W_hi.x_lo + W_lo.x_hi).  Sampling, encodings, heads, compositing and resampling stay fp32 and are the
  * same code as swnerf_render_pass.  NOT the parity path (that is fp32 MFMA, bit-comparable to torch's CPU kernels up to
- * summation order); measured deviation from it: DESIGN.md.  Static canonical net only (SWNERF_NET_CANON);
- * args->packed = a blob from swnerf_pack_net_x3 (swnerf_packed_x3_floats() floats), built from the same 24 tensors
- * plus the fp32 blob of swnerf_pack_net (its bias tiles are copied).  terms: 3 = bf16x3, 1 = plain bf16 (hi only). */
+ * summation order); measured deviation from it: DESIGN.md 7c.  Inference only; both net kinds.
+ * args->packed = a blob from swnerf_pack_net_x3_kind (swnerf_packed_x3_floats_kind(kind) floats), built from the same
+ * tensors plus the fp32 blob of swnerf_pack_net for that kind (its bias tiles are copied).
+ * terms: 3 = bf16x3, 1 = plain bf16 (hi halves only; a yardstick, ~37 dB).
+ * swnerf_packed_x3_floats / swnerf_pack_net_x3: the SWNERF_NET_CANON forms. */
+size_t swnerf_packed_x3_floats_kind(int kind);
+int swnerf_pack_net_x3_kind(int kind, const float* const* params /*HOST*/, int L_pos, int L_dir, int L_time,
+                            const float* packed_fp32, float* packed_x3, void* stream);
 size_t swnerf_packed_x3_floats(void);
 int swnerf_pack_net_x3(const float* const* params /*HOST*/, int L_pos, int L_dir, const float* packed_canon,
                        float* packed_x3, void* stream);

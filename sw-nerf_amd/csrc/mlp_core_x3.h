@@ -62,9 +62,16 @@ struct XStream {
 // One chunk = 4 DMA instructions per wave.  Back to back they stall the wave while the matrix pipe runs dry (each
 // waits for the address path), so in the steady state they go out ONE PER GROUP, each behind a group's MFMAs
 // (x3_issue_part); only the priming chunks are issued in one go.
+// wave-uniform by construction; said explicitly, because in the two-net kernel the compiler's divergence analysis gives
+// up on the pointer and hands the "s" operand of the DMA statement a VGPR pair
+__device__ __forceinline__ const char* x3_uniform(const char* p) {
+    const unsigned long long v = (unsigned long long)(size_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>((size_t)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ void x3_issue_part(XStream& xs, int i) {
 #ifndef X3_EXP_NODMA                             // timing experiment: only the priming chunks are ever loaded
-    ws_dma(xs.gnext + i * 1024, xs.voff, xs.idst + i * 1024);
+    ws_dma(x3_uniform(xs.gnext) + i * 1024, xs.voff, __builtin_amdgcn_readfirstlane(xs.idst) + i * 1024);
 #endif
     if (i == 3) xs.gnext += X3_CHUNK_BYTES;
 }
@@ -75,7 +82,7 @@ __device__ __forceinline__ void x3_issue_begin(XStream& xs) {
 __device__ __forceinline__ void x3_issue(XStream& xs) {
     x3_issue_begin(xs);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ws_dma(xs.gnext + i * 1024, xs.voff, xs.idst + i * 1024);
+    for (int i = 0; i < 4; ++i) ws_dma(x3_uniform(xs.gnext) + i * 1024, xs.voff, __builtin_amdgcn_readfirstlane(xs.idst) + i * 1024);
     xs.gnext += X3_CHUNK_BYTES;
 }
 
@@ -336,4 +343,100 @@ __device__ __forceinline__ void x3_canon(float px, float py, float pz, int h, co
         rgb[o] = s + __shfl_xor(s, 32, 64) + hb[1 + o];
     }
     X3_PROBE(1, q8);
+}
+
+// DirectTemporalNeRF (model.py:128-151) on one 32-row tile: ONE body for both nets, like the fp32 kernel - `deform`
+// selects the deformation net (layer 0 also takes gamma(t); 7 more layers; head = _time_out, 3 outputs in head[]) or the
+// canonical net (as x3_canon; head[0] = sigma, rgb[]).  gamma(d) is evaluated here from the view direction (no LDS tile:
+// the two bias-tile sets need its room).
+template <int TERMS>
+__device__ __forceinline__ void x3_net_dn(float px, float py, float pz, float ft, bool deform, int h, float v0, float v1, float v2,
+                                          float (&head)[3], float (&rgb)[3], XStream& xs) {
+    u32x4 bhi[16], blo[16];
+    f32x16 acc[8];
+    {
+        f32x16 emb[2];
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        pe_pos(px, py, pz, h, emb);
+        u32x4 ehi[6], elo[6];
+        x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+        x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+        if (deform) {                                               // cat[new_pts, t] (model.py:129)
+            f32x16 te;
+            pe_time(ft, h, te);
+            x3_split<false>(te, ehi[4], elo[4], ehi[5], elo[5]);
+            x3_seg<8, 0, 6, SEG_BIAS, TERMS>(acc, ehi, elo, xs);
+        } else {
+            x3_seg<8, 0, 4, SEG_BIAS, TERMS>(acc, ehi, elo, xs);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], 0.f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float* hb = nullptr;
+    const int last = deform ? 7 : 8;                                // the canonical net's feature_linear rides as layer 8
+#pragma nounroll
+    for (int l = 1; l <= last; ++l) {
+        x3_seg<8, 0, 16, SEG_BIAS, TERMS>(acc, bhi, blo, xs);
+        if (l == 5) {
+            f32x16 emb[2];
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+            pe_pos(px, py, pz, h, emb);
+            u32x4 ehi[4], elo[4];
+            x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+            x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+            x3_seg<8, 0, 4, SEG_ACC, TERMS>(acc, ehi, elo, xs);
+        }
+        if (l == 7) {
+            // the head on relu(h_7) in fp32: alpha_linear (1 output) or _time_out (3), weight tiles then the head-bias tile
+            const int nout = deform ? 3 : 1;
+#pragma nounroll
+            for (int o = 0; o < nout; ++o) {
+                float s = 0.f;
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    f32x16 t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = relu1(acc[n][r]);
+                    s = x3_head_part(t, xs.bias + (o * 8 + n) * SW_BIAS_TILE_FLOATS, s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                s += __shfl_xor(s, 32, 64);
+                const float v = s + xs.bias[nout * 8 * SW_BIAS_TILE_FLOATS + o];
+                if (o == 0) head[0] = v; else if (o == 1) head[1] = v; else head[2] = v;
+            }
+            hb = xs.bias + nout * 8 * SW_BIAS_TILE_FLOATS;           // canonical: [b_alpha, b_r, b_g, b_b]
+            xs.bias += (nout * 8 + 1) * SW_BIAS_TILE_FLOATS;
+        }
+        const float floor = (l == 8) ? -__builtin_inff() : 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], floor);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (deform) return;
+    f32x16 hv[4];
+    x3_seg<4, 0, 16, SEG_BIAS, TERMS>(hv, bhi, blo, xs);
+    {
+        f32x16 demb;
+        pe_dir(v0, v1, v2, h, demb);
+        u32x4 dhi[2], dlo[2];
+        x3_split<false>(demb, dhi[0], dlo[0], dhi[1], dlo[1]);
+        x3_seg<4, 0, 2, SEG_ACC, TERMS>(hv, dhi, dlo, xs);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = relu1(hv[n][r]);
+            s = x3_head_part(t, xs.bias + (o * 4 + n) * SW_BIAS_TILE_FLOATS, s);
+        }
+        rgb[o] = s + __shfl_xor(s, 32, 64) + hb[1 + o];
+    }
 }

@@ -95,13 +95,18 @@ template <bool DNERF, bool TRAIN> struct PassLds {
 };
 // PREC != 0 (bf16x3 / bf16 pass, mlp_core_x3.h): bias tiles | the workgroup's shared weight ring | per wave: gamma(d)
 // tile + depth slots | per wave: resampling scratch
-#define X3_WAVE_FLOATS (16 * 64 + SW_ZSLOT_FLOATS)
-#define X3_LDS_FIXED_FLOATS (SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS + X3_RING_FLOATS + 4 * X3_WAVE_FLOATS)
+// (D-NeRF: both bias-tile sets, and no gamma(d) tile - x3_net_dn evaluates it - so that the resampling scratch still fits)
+template <bool DNERF> struct X3Lds {
+    static constexpr int BIAS = DNERF ? SW_LDS_BIAS_FLOATS : SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    static constexpr int DIR = DNERF ? 0 : 16 * 64;
+    static constexpr int WAVE = DIR + SW_ZSLOT_FLOATS;
+    static constexpr int FIXED = BIAS + X3_RING_FLOATS + 4 * WAVE;
+};
 
 // PREC: 0 = fp32 MFMA (mlp_core.h, the parity path); 3 = bf16x3, 1 = plain bf16 (mlp_core_x3.h; static net, inference)
 template <bool DNERF, bool TRAIN = false, int PREC = 0>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
-    static_assert(PREC == 0 || (!DNERF && !TRAIN), "the bf16 paths cover the static inference pass");
+    static_assert(PREC == 0 || !TRAIN, "the bf16 paths cover the inference passes");
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     SW_STAMP(probe_start);
     const swnerf_pass_args& a = P.a;
@@ -115,12 +120,12 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     if (PREC == 0 && ray_id >= a.n_rays) return; // wave-uniform
     const int64_t ray = ghost ? a.n_rays - 1 : ray_id;
     const float* lds_bias = lds_all;
-    float* lds_ring = PREC ? lds_all + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS
+    float* lds_ring = PREC ? lds_all + X3Lds<DNERF>::BIAS
                            : lds_all + PassLds<DNERF, TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS;
     float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
-    float* lds_x3w = lds_ring + X3_RING_FLOATS + wv * X3_WAVE_FLOATS;
+    float* lds_x3w = lds_ring + X3_RING_FLOATS + wv * X3Lds<DNERF>::WAVE;
     float* lds_dir = PREC ? lds_x3w : lds_emb + 2 * 16 * 64;
-    float* lds = PREC ? lds_all + X3_LDS_FIXED_FLOATS + wv * SW_LDS_WAVE_FLOATS
+    float* lds = PREC ? lds_all + X3Lds<DNERF>::FIXED + wv * SW_LDS_WAVE_FLOATS
                       : lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
     float* wc = lds + SW_LDS_SC;                 // [S]   compositing weights
@@ -136,7 +141,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const float v0 = rb[a.cols - 3], v1 = rb[a.cols - 2], v2 = rb[a.cols - 1];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
 
-    {   // once per ray: the view-direction encoding, parked in LDS (see tile_park)
+    if (!(PREC && DNERF)) {   // once per ray: the view-direction encoding, parked in LDS (see tile_park)
         f32x16 demb;
         pe_dir(v0, v1, v2, h, demb);
         tile_park(lds_dir, lane, demb);
@@ -147,7 +152,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     else ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
     const float* zrow = a.z_vals ? a.z_vals + ray * S : nullptr;
-    const float* zslot = PREC ? lds_x3w + 16 * 64 : lds_emb + SW_EMB_LDS_FLOATS;
+    const float* zslot = PREC ? lds_x3w + X3Lds<DNERF>::DIR : lds_emb + SW_EMB_LDS_FLOATS;
     const unsigned zslot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)zslot);
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
     double Tc = 1.0;                              // transmittance carried across tiles
@@ -221,6 +226,26 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             }
             tile_fetch(lds_dir, lane, demb);
             canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+        } else if (DNERF && PREC != 0) {
+            if constexpr (DNERF && PREC != 0) {
+#pragma nounroll
+                for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
+                    x3_net_dn<PREC>(px, py, pz, ft, pass == 0, h, v0, v1, v2, head, rgb, xs);
+                    if (pass == 0) {
+                        const float ex = head[0], ey = head[1], ez = head[2];
+                        if (a.dx && live && h == 0) {
+                            float* o = a.dx + (ray * S + s) * 3;
+                            o[0] = ex; o[1] = ey; o[2] = ez;
+                        }
+                        px = px + ex; py = py + ey; pz = pz + ez;        // re-embedded inside the canonical pass
+                    }
+                }
+                if (!P.two_pass && a.dx && live && h == 0) {
+                    float* o = a.dx + (ray * S + s) * 3;
+                    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+                }
+                x3_rewind(xs, P.two_pass ? SW_X3_DEFORM_CHUNKS + SW_X3_CANON_CHUNKS : SW_X3_CANON_CHUNKS, lds_bias, lane);
+            }
         } else if (DNERF) {
 #pragma nounroll
             for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {

@@ -91,6 +91,14 @@
 // blob: [weight stream + tail][the canonical bias tiles, as in the fp32 blob]
 #define SW_X3_FLOATS (SW_X3_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
+// D-NeRF: deformation net groups D0 8x6 (gamma(x) then gamma(t)) | D1..D4 | D5 8x20 | D6 D7, then the canonical groups
+#define SW_X3_DEFORM_GROUPS (48 + 4 * 128 + 160 + 2 * 128)
+#define SW_X3_DEFORM_CHUNKS (SW_X3_DEFORM_GROUPS / 8)
+#define SW_X3_DNERF_W_FLOATS ((SW_X3_DEFORM_CHUNKS + SW_X3_CANON_CHUNKS + SW_X3_TAIL_CHUNKS) * SW_X3_CHUNK_FLOATS)
+// blob DNERF: [deform + canon stream + tail][deform bias][canon bias] then a full CANON x3 blob (the t == 0 branch)
+#define SW_X3_DNERF_A_FLOATS (SW_X3_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
+#define SW_X3_DNERF_FLOATS (SW_X3_DNERF_A_FLOATS + SW_X3_FLOATS)
+
 // C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile
 SW_HD int sw_frow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

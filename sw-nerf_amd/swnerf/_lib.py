@@ -20,7 +20,8 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
            "swnerf_render_pass_train_dnerf", "swnerf_render_pass_backward_dnerf", "swnerf_unslot_grad_time",
            "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask",
-           "swnerf_packed_x3_floats", "swnerf_pack_net_x3", "swnerf_render_pass_x3"]
+           "swnerf_packed_x3_floats", "swnerf_pack_net_x3", "swnerf_render_pass_x3",
+           "swnerf_packed_x3_floats_kind", "swnerf_pack_net_x3_kind"]
 BWD_CANON, BWD_CANON_INPUT_GRAD, BWD_DEFORM, BWD_DNERF_FUSED = 0, 1, 2, 3
 
 
@@ -112,6 +113,9 @@ def lib():
     L.swnerf_packed_x3_floats.argtypes = []
     L.swnerf_pack_net_x3.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_void_p]
     L.swnerf_render_pass_x3.argtypes = [POINTER(PassArgs), c_int, c_void_p]
+    L.swnerf_packed_x3_floats_kind.restype = c_size_t
+    L.swnerf_packed_x3_floats_kind.argtypes = [c_int]
+    L.swnerf_pack_net_x3_kind.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
                         "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):

@@ -379,19 +379,17 @@ class _PackedMixin:
         return kind, self._packed, Lp, Ld, Lt
 
     def packed_x3(self):
-        """The bf16x3 weight stream of the static canonical net (include/swnerf.h swnerf_pack_net_x3), cached like packed()."""
-        kind, packed, Lp, Ld, _ = self.packed()
-        if kind != _lib.NET_CANON:
-            raise NotImplementedError("swnerf: the bf16x3 pass covers the static canonical net (vallina_NeRF / NeRFOriginal)")
+        """The bf16x3 weight stream of this net (include/swnerf.h swnerf_pack_net_x3_kind), cached like packed()."""
+        kind, packed, Lp, Ld, Lt = self.packed()
         if getattr(self, "_pack_x3_key", None) != self._pack_key:
             L = _lib.lib()
             _, names, _, _, _ = self._pack_params()
             sd = dict(self.named_parameters())
             ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous()
-                    for p in (sd[n] for n in names[:24])]
-            arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in ps32])
-            buf = torch.empty(L.swnerf_packed_x3_floats(), dtype=torch.float32, device=packed.device)
-            _lib.check(L.swnerf_pack_net_x3(arr, Lp, Ld, _lib.ptr(packed), _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_x3")
+                    for p in (sd[n] for n in names)]
+            arr = (ctypes.c_void_p * len(ps32))(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_x3_floats_kind(kind), dtype=torch.float32, device=packed.device)
+            _lib.check(L.swnerf_pack_net_x3_kind(kind, arr, Lp, Ld, Lt, _lib.ptr(packed), _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_x3")
             self._pack_x3, self._pack_x3_key = buf, self._pack_key
         return self._pack_x3, Lp, Ld
 

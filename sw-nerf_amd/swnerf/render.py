@@ -107,8 +107,12 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
 
 # Arithmetic of the fused INFERENCE pass of the static nets: "fp32" (fp32 MFMA: the parity path, the default and what
 # bench.py's headline measures), "bf16x3" (split-bf16 MFMA with fp32 accumulation, ~16 significant bits per operand; see
-# include/swnerf.h swnerf_render_pass_x3) or "bf16" (plain bf16 operands).  Opt-in: set_precision() or SWNERF_PRECISION.
-_PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16": 1}
+# include/swnerf.h swnerf_render_pass_x3), "bf16x3-fine" (below) or "bf16" (plain bf16 operands, a yardstick).
+# Opt-in: set_precision() or SWNERF_PRECISION.
+# "bf16x3-fine": fp32 for a pass that feeds the hierarchical resampling (the inverse CDF is a discontinuous function of the
+# coarse weights, so last-bit differences there move fine samples), bf16x3 for every other pass: the depths, rgb0 and z_std
+# are then exactly the fp32 path's and the image differs by the MLP rounding alone.
+_PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16x3-fine": 3, "bf16": 1}
 PRECISION = os.environ.get("SWNERF_PRECISION", "fp32")
 
 
@@ -125,14 +129,14 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
                 want=("rgb_map", "disp_map", "acc_map"), n_importance=0, u=None, run_deform=True, precision=None):
     """One launch of `swnerf_render_pass` (include/swnerf.h).  Returns a dict of the requested
     outputs among rgb_map disp_map acc_map depth_map weights raw dx z_out, plus z_fine/z_std
-    when n_importance > 0.  precision: None = the module setting (PRECISION); the bf16 paths exist for the static
-    canonical net, any other net runs fp32."""
+    when n_importance > 0.  precision: None = the module setting (PRECISION)."""
     kind, packed, Lp, Ld, Lt = net.packed()
-    terms = _PRECISIONS[PRECISION if precision is None else precision]
-    if terms and kind == _lib.NET_CANON:
-        packed, _, _ = net.packed_x3()
-    else:
+    mode = PRECISION if precision is None else precision
+    terms = _PRECISIONS[mode]
+    if mode == "bf16x3-fine" and n_importance > 0:
         terms = 0
+    if terms:
+        packed, _, _ = net.packed_x3()
     rb = _lib.dev_f32(ray_batch, "ray_batch")
     N, cols = rb.shape
     S = int(n_samples)

@@ -114,6 +114,14 @@ def test_x3_resampling_and_full_render(sw, dev, nets):
         finally:
             sw.render.set_precision(prev)
         assert prev == "fp32" and sw.render.PRECISION == "fp32"
+        # "bf16x3-fine": the pass that feeds the resampling stays fp32 -> rgb0 / z_std bit-identical, the image > 95 dB
+        sw.render.set_precision("bf16x3-fine")
+        try:
+            mix = sw.render.render(40, 56, K, chunk=1024 * 32, c2w=T(c2w).to(dev), **kw)
+        finally:
+            sw.render.set_precision("fp32")
+        assert torch.equal(mix[3]["rgb0"], ref[3]["rgb0"]) and torch.equal(mix[3]["z_std"], ref[3]["z_std"])
+        assert not torch.equal(mix[0], ref[0]) and psnr(ref[0], mix[0]) > 95.0
         assert not torch.equal(ref[0], got[0])                          # it really ran the other path
         assert psnr(ref[0], got[0]) > 50.0
         assert psnr(ref[3]["rgb0"], got[3]["rgb0"]) > 95.0              # the coarse image has no resampling in front of it
@@ -148,13 +156,50 @@ def test_x3_blob_follows_the_weights(sw, dev, nets):
     assert float((a - b).abs().max()) > 1e-3 and float((b - ref).abs().max()) < 1e-4
 
 
-def test_x3_rejects_what_it_does_not_cover(sw, dev):
-    """D-NeRF nets run fp32 whatever the switch says (render_pass falls back by kind); the C entry refuses them."""
+def test_x3_dnerf_tracks_fp32_pass(sw, dev):
+    """DirectTemporalNeRF (deformation net, re-embedding of x + dx, canonical net) in one bf16x3 pass, t = 0.5, and the
+    `t == 0 and zero_canonical` branch (canonical net alone).  Measured on MI355X: t = 0.5: max |d rgb| 1.2e-4, 96 dB;
+    t = 0: 8.8e-6, 115 dB."""
+    import swnerf.render_dnerf  # noqa
+    e10, _ = sw.embedder.get_embedder(10, 3, 0)
+    dn = sw.model.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27,
+                                   input_ch_time=21, use_viewdirs=True, embed_fn=e10, zero_canonical=True)
+    dn.load_state_dict({k: T(v) for k, v in cases.weights_dnerf().items()})
+    dn = dn.to(dev).eval()
+    g = cases.g8_inputs(n=515)
+    want = ("rgb_map", "acc_map", "raw", "dx", "weights")
+    for t, deform in ((0.5, True), (0.0, False)):
+        rb = sw.render.pack_ray_batch(T(g["rays_o"]).to(dev), T(g["rays_d"]).to(dev), g["near"], g["far"], frame_time=t)
+        with torch.no_grad():
+            a = sw.render.render_pass(rb, dn, 64, want=want, white_bkgd=True, run_deform=deform, n_importance=128, precision="fp32")
+            b = sw.render.render_pass(rb, dn, 64, want=want, white_bkgd=True, run_deform=deform, n_importance=128, precision="bf16x3")
+            fa = sw.render.render_pass(rb, dn, 192, z_vals=a["z_fine"], want=want, white_bkgd=True, run_deform=deform, precision="fp32")
+            fb = sw.render.render_pass(rb, dn, 192, z_vals=a["z_fine"], want=want, white_bkgd=True, run_deform=deform, precision="bf16x3")
+        for x, y in ((a, b), (fa, fb)):
+            assert float((x["dx"] - y["dx"]).abs().max()) < 5e-5, float((x["dx"] - y["dx"]).abs().max())
+            if not deform:
+                assert float(y["dx"].abs().max()) == 0.0
+            # the canonical net sees gamma(x + dx) up to the band 2^9: a 4e-6 difference in dx is a 2e-3 phase difference
+            # there, so raw moves by ~1e-3 where the static net's moves by 1e-4 (the fp32 pass shows the same
+            # conditioning against the CPU oracle: 62 dB on C5 against 81 dB on C4)
+            scale = max(float(x["raw"].abs().max()), 1.0)
+            m = dict(raw=float((x["raw"] - y["raw"]).abs().max()), **{k: float((x[k] - y[k]).abs().max()) for k in ("rgb_map", "acc_map", "weights")},
+                     psnr=psnr(x["rgb_map"], y["rgb_map"]))
+            print(f"t={t} S={x['raw'].shape[1]}: {m}")
+            assert m["raw"] < (1e-3 if deform else 1e-4) * scale, m
+            assert max(m["rgb_map"], m["acc_map"], m["weights"]) < (5e-4 if deform else 1e-4), m
+            assert m["psnr"] > (80.0 if deform else 95.0), m
+        assert bool((b["z_fine"][:, 1:] >= b["z_fine"][:, :-1]).all())
+
+
+def test_x3_argument_checks(sw, dev):
     from swnerf import _lib
     a = _lib.PassArgs()
     buf = torch.zeros(64, device=dev)
-    a.ray_batch, a.n_rays, a.cols, a.kind, a.packed, a.n_samples = buf.data_ptr(), 1, 12, _lib.NET_DNERF, buf.data_ptr(), 64
-    assert _lib.lib().swnerf_render_pass_x3(a, 3, None) == -2
-    a.kind, a.cols = _lib.NET_CANON, 11
-    assert _lib.lib().swnerf_render_pass_x3(a, 2, None) == -1
-    assert b"terms" in _lib.lib().swnerf_last_error()
+    a.ray_batch, a.n_rays, a.cols, a.kind, a.packed, a.n_samples = buf.data_ptr(), 1, 11, _lib.NET_DNERF, buf.data_ptr(), 64
+    assert _lib.lib().swnerf_render_pass_x3(a, 3, None) == -1 and b"frame_time" in _lib.lib().swnerf_last_error()
+    a.kind = 7
+    assert _lib.lib().swnerf_render_pass_x3(a, 3, None) == -1
+    a.kind = _lib.NET_CANON
+    assert _lib.lib().swnerf_render_pass_x3(a, 2, None) == -1 and b"terms" in _lib.lib().swnerf_last_error()
+    assert _lib.lib().swnerf_packed_x3_floats_kind(7) == 0

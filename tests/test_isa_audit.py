@@ -110,3 +110,41 @@ def test_weight_gradient_gemm_isa(tmp_path):
         assert "scratch_" not in body[:body.index("s_endpgm")]
         seen += 1
     assert seen == 7
+
+
+def test_x3_kernels_isa(tmp_path):
+    """The bf16x3 / bf16 pass (csrc/mlp_core_x3.h): the properties its shared weight ring relies on.
+      * no scratch at all (a scratch reload drains the DMA ring: scratch shares vmcnt),
+      * static MFMA count = groups of the unrolled bodies x terms: L0 (32) + the layer-loop body (128) + its skip part (32)
+        + the view layer (64 + 8) (+ the deformation net's layer 0, 48, in the D-NeRF instantiations),
+      * one bare s_barrier per chunk of 8 groups (+ the one that publishes chunk 0), each behind a counted vmcnt wait -
+        never a `vmcnt(0)` between the first and the last MFMA (it would wait for the whole ring),
+      * the refill of a chunk is 4 LDS-DMA instructions, issued one per group."""
+    import isa_audit
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = tmp_path / "x3.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-S", "--cuda-device-only",
+                    "-o", str(out), os.path.join(ROOT, "sw-nerf_amd", "csrc", "x3_kernels.hip")], check=True, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    seen = 0
+    for name, body in isa_audit.kernels(text):
+        if "render_pass_kernel" not in name:
+            continue
+        seen += 1
+        terms = 3 if "Li3E" in name else 1
+        groups = 32 + 128 + 32 + 64 + 8
+        if "kernelILb1" in name:                    # D-NeRF: + the deformation net's layer 0 (gamma(x) and gamma(t): 8 x 6)
+            groups += 48
+        lines = body.split("\n")
+        mf = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mf) == groups * terms, (name, len(mf))
+        assert "v_mfma_f32_32x32x2_f32" not in body
+        chunks = groups // 8
+        assert len(re.findall(r"\bs_barrier\b", body)) == chunks + 1 + 1, name         # + chunk 0's + bias_to_lds's __syncthreads
+        dma = len(re.findall(r"global_load_lds_dwordx4", body))
+        assert dma == 4 * chunks + 4 * 4 + 3, (name, dma)                              # + priming: 4 chunks and 3 parts of the fifth
+        hot = "\n".join(lines[mf[0]:mf[-1]])
+        assert "vmcnt(0)" not in hot and "scratch_" not in body, name
+        m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", text, re.S)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(0)).group(1)) == 0
+    assert seen == 4
