@@ -41,6 +41,7 @@ for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
 
 FLOP_PER_ROW = 2 * 593408           # MACs of one (ray,sample) row through the 8x256 net
 FLOP_PER_ROW_DEFORM = 2 * 497152    # ... through the deformation net (D-NeRF, t != 0)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); only used by --precision bf16x3 lines
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 N_RAND, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
 DEFAULT_STEPS = {"C2": (50, 5), "C4": (5, 1), "C5": (10, 2)}
@@ -54,6 +55,9 @@ def parse_args():
     ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs block")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x3-fine"], default="fp32",
+                    help="arithmetic of the fused passes; fp32 (default) is the metric BASELINE.json names and the only one the "
+                         "driver measures - the others are the opt-in bf16x3 paths (DESIGN.md 7c), labelled as such in the line")
     args = ap.parse_args()
     ds, dw = DEFAULT_STEPS[args.config]
     args.steps = ds if args.steps is None else args.steps
@@ -345,6 +349,8 @@ def worker(args):
     if world > 1:
         dist.barrier()
     from swnerf import synth, render, parallel
+    render.set_precision(args.precision)
+    x3 = args.precision != "fp32"
 
     cfg = args.config
     sc = build_scene(cfg, dev, rank)
@@ -431,7 +437,7 @@ def worker(args):
     result = {
         "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_step * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if not x3 else args.precision,
         "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo; not a measurement)" if rehearsal else ""),
         "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if world > 1 else ""),
                    "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE,
@@ -442,6 +448,14 @@ def worker(args):
                      "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
                      "step_frac": rays_per_step / world * sc["flop_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
     }
+    if x3:
+        # the fine pass runs 3 bf16 MFMAs per product: price the matrix work it really does against the dense bf16 peak
+        r = result["roofline"]
+        r.update({"achieved": 3 * achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 3 * achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                  "flop_per_launch": 3 * fine_flop, "step_frac": None,
+                  "note": "bf16x3: achieved = 3 x the algorithmic FLOPs of the fine pass / its launch time; NOT the BASELINE metric's dtype"})
+        result["metric"] += f" [{args.precision} arithmetic, opt-in]"
+        args.no_extra = True
     assert result["n_gpus"] == args.gpus
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
