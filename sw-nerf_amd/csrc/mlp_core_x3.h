@@ -440,3 +440,244 @@ __device__ __forceinline__ void x3_net_dn(float px, float py, float pz, float ft
         rgb[o] = s + __shfl_xor(s, 32, 64) + hb[1 + o];
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same canonical net with the split phase HIDDEN under the matrix pipe (software pipeline across layers).
+// With k-block-major order layer L+1 needs tile t of layer L's output (k-blocks 2t, 2t+1) only when it reaches them, so
+// the (hi, lo) split of tile t+1 - 8 pairs of values, ~10 VALU operations each - is spread over the 2*NT groups
+// (6*NT MFMAs) that consume tile t.  Layer L's accumulators therefore stay fp32 while layer L+1 runs: two accumulator
+// sets take turns (256 registers), but only a two-tile window of B operands exists at any time (32 registers).
+// The accumulators of a layer start from its bias tiles by way of the first MFMA's srcC (read from LDS one group ahead),
+// not by a 128-register init phase.
+struct X3Win { u32x4 hi[2], lo[2]; };     // the two k-blocks of ONE source tile
+
+// one pair (values 2q, 2q+1) of source tile `v` -> window w; optionally the fp32 head: s += wt[..] * relu(value)
+template <int Q>
+__device__ __forceinline__ void x3_split_pair(const f32x16& v, float floor, X3Win& w, const float* head_w, float& head_s) {
+    const float a = x3_floor(v[2 * Q], floor), b = x3_floor(v[2 * Q + 1], floor);
+    const unsigned h2 = x3_cvt_pk(a, b);
+    const float ra = a - __uint_as_float(h2 << 16), rb = b - __uint_as_float(h2 & 0xffff0000u);
+    const unsigned l2 = x3_cvt_pk(ra, rb);
+    w.hi[Q >> 2][Q & 3] = h2; w.lo[Q >> 2][Q & 3] = l2;
+    if (head_w) { head_s = fmaf(head_w[2 * Q], a, head_s); head_s = fmaf(head_w[2 * Q + 1], b, head_s); }   // wave-uniform branch
+}
+template <int Q0, int Q1>
+__device__ __forceinline__ void x3_split_pairs(const f32x16& v, float floor, X3Win& w, const float* head_w, float& head_s) {
+    if constexpr (Q0 < Q1) {
+        x3_split_pair<Q0>(v, floor, w, head_w, head_s);
+        x3_split_pairs<Q0 + 1, Q1>(v, floor, w, head_w, head_s);
+    }
+}
+
+// groups of one 256-wide layer: dst[n] = bias_n + sum_kb W(n,kb) . split(src)[kb];  NT output tiles (8, or 4 for the view layer)
+template <int G, int NT, int TERMS>
+__device__ __forceinline__ void x3_pgroups(f32x16 (&dst)[NT], const f32x16 (&src)[8], float floor, X3Win& cur, X3Win& nxt, f32x16& binit,
+                                           const float* head_w, float& head_s, XStream& xs) {
+    constexpr int NG = NT * 16;
+    if constexpr (G < NG) {
+        constexpr int g = G % X3_CHUNK_GROUPS, kb = G / NT, n = G % NT, t = kb / 2, c = kb % 2, j = G % (2 * NT);
+        if constexpr (g == X3_CHUNK_GROUPS - 1 - X3_AHEAD) x3_advance(xs);
+        u32x4 nhi, nlo;
+        if constexpr (g + X3_AHEAD >= X3_CHUNK_GROUPS) x3_read(xs.rd_next + (g + X3_AHEAD - X3_CHUNK_GROUPS) * X3_GROUP_BYTES, nhi, nlo);
+        else x3_read(xs.rd + (g + X3_AHEAD) * X3_GROUP_BYTES, nhi, nlo);
+        f32x16 bnext;
+        if constexpr (kb == 0 && n + 1 < NT) {                  // the next tile's bias, one group ahead of the MFMA that starts from it
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xs.bias + (n + 1) * SW_BIAS_TILE_FLOATS + 4 * q);
+                bnext[4 * q + 0] = v[0]; bnext[4 * q + 1] = v[1]; bnext[4 * q + 2] = v[2]; bnext[4 * q + 3] = v[3];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kb == 0) dst[n] = x3_mfma<TERMS>(xs.ahi, xs.alo, cur.hi[c], cur.lo[c], binit);
+        else dst[n] = x3_mfma<TERMS>(xs.ahi, xs.alo, cur.hi[c], cur.lo[c], dst[n]);
+        // the slice of tile t+1's split that rides behind this group's MFMAs (VALU issue slots the matrix pipe leaves free)
+        if constexpr (t + 1 < 8) {
+            constexpr int per = 8 / (2 * NT) > 0 ? 8 / (2 * NT) : 1;          // pairs per group: NT=4 -> 1; NT=8 -> one every 2nd group
+            if constexpr (2 * NT <= 8) x3_split_pairs<j * per, j * per + per>(src[t + 1], floor, nxt, head_w ? head_w + (t + 1) * SW_BIAS_TILE_FLOATS : nullptr, head_s);
+            else if constexpr (j % 2 == 1) x3_split_pairs<j / 2, j / 2 + 1>(src[t + 1], floor, nxt, head_w ? head_w + (t + 1) * SW_BIAS_TILE_FLOATS : nullptr, head_s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            constexpr int part = (g - (X3_CHUNK_GROUPS - 1 - X3_AHEAD) + X3_CHUNK_GROUPS) % X3_CHUNK_GROUPS;
+            if constexpr (part < 4) {
+                x3_issue_part(xs, part);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (g == X3_CHUNK_GROUPS - 1) xs.rd = xs.rd_next;
+#if X3_AHEAD == 2
+        xs.ahi = xs.a2hi; xs.alo = xs.a2lo; xs.a2hi = nhi; xs.a2lo = nlo;
+#else
+        xs.ahi = nhi; xs.alo = nlo;
+#endif
+        if constexpr (kb == 0 && n + 1 < NT) binit = bnext;
+        if constexpr (j == 2 * NT - 1 && t + 1 < 8) cur = nxt;
+        x3_pgroups<G + 1, NT, TERMS>(dst, src, floor, cur, nxt, binit, head_w, head_s, xs);
+    }
+}
+
+// one layer: dst = W . act(src) + b, act = max(., floor).  head_w != NULL: also head_s = sum_f head_w[f] * act(src)[f] (this
+// lane's 128 features; bias-style weight tiles).  Consumes NT bias tiles at xs.bias + bias_skip tiles.
+template <int NT, int TERMS>
+__device__ __forceinline__ void x3_player(f32x16 (&dst)[NT], const f32x16 (&src)[8], float floor, const float* head_w, float& head_s,
+                                          int bias_skip, XStream& xs) {
+    X3Win cur, nxt;
+    xs.bias += bias_skip * SW_BIAS_TILE_FLOATS;
+    f32x16 binit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xs.bias + 4 * q);
+        binit[4 * q + 0] = v[0]; binit[4 * q + 1] = v[1]; binit[4 * q + 2] = v[2]; binit[4 * q + 3] = v[3];
+    }
+    x3_split_pairs<0, 8>(src[0], floor, cur, head_w, head_s);        // tile 0 up front: the only exposed part of the split
+    x3_pgroups<0, NT, TERMS>(dst, src, floor, cur, nxt, binit, head_w, head_s, xs);
+    xs.bias += NT * SW_BIAS_TILE_FLOATS;
+}
+
+template <int TERMS>
+__device__ __forceinline__ void x3_canon_pipe(float px, float py, float pz, int h, const float* lds_dir, int lane,
+                                              float& sigma, float (&rgb)[3], XStream& xs) {
+    f32x16 A[8], B[8];
+    float dummy = 0.f;
+    {   // pts_linears[0] on gamma(x): the accumulators start from the bias tiles (the one init phase left)
+        f32x16 emb[2];
+        pe_pos(px, py, pz, h, emb);
+        u32x4 ehi[4], elo[4];
+        x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+        x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+        x3_seg<8, 0, 4, SEG_BIAS, TERMS>(A, ehi, elo, xs);
+    }
+    float hs = 0.f;
+    const float* hb = nullptr;
+    // layer pairs (1,2) (3,4) (5,6) (7, feature_linear): odd layers A -> B, even layers B -> A
+#pragma nounroll
+    for (int i = 0; i < 4; ++i) {
+        x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);
+        if (i == 2) {                                               // layer 5: ... then gamma(x) (model.py:45-46)
+            f32x16 emb[2];
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+            pe_pos(px, py, pz, h, emb);
+            u32x4 ehi[4], elo[4];
+            x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+            x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+            x3_seg<8, 0, 4, SEG_ACC, TERMS>(B, ehi, elo, xs);
+        }
+        // i == 3: this is feature_linear on relu(h_7), and alpha_linear rides on the split of h_7 (8 weight tiles + the
+        // head-bias tile sit in front of feature_linear's bias tiles)
+        const float* hw = (i == 3) ? xs.bias : nullptr;
+        if (i == 3) hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;
+        x3_player<8, TERMS>(A, B, 0.f, hw, hs, i == 3 ? 9 : 0, xs);
+    }
+    hs += __shfl_xor(hs, 32, 64);
+    sigma = hs + hb[0];
+    f32x16 hv[4];
+    x3_player<4, TERMS>(hv, A, -__builtin_inff(), nullptr, dummy, 0, xs);    // views_linears[0]: the feature (no activation) ...
+    {
+        f32x16 demb;
+        tile_fetch(lds_dir, lane, demb);
+        u32x4 dhi[2], dlo[2];
+        x3_split<false>(demb, dhi[0], dlo[0], dhi[1], dlo[1]);
+        x3_seg<4, 0, 2, SEG_ACC, TERMS>(hv, dhi, dlo, xs);                  // ... then gamma(d)
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = relu1(hv[n][r]);
+            s = x3_head_part(t, xs.bias + (o * 4 + n) * SW_BIAS_TILE_FLOATS, s);
+        }
+        rgb[o] = s + __shfl_xor(s, 32, 64) + hb[1 + o];
+    }
+}
+
+// DirectTemporalNeRF with the same software pipeline: `deform` selects the deformation net (layer 0 also takes gamma(t);
+// layers 1..7; head = _time_out on relu(h_7), computed on the spot - nothing follows to ride on) or the canonical net
+// (as x3_canon_pipe).  One body for both (see x3_net_dn).
+template <int TERMS>
+__device__ __forceinline__ void x3_net_dn_pipe(float px, float py, float pz, float ft, bool deform, int h, float v0, float v1, float v2,
+                                               float (&head)[3], float (&rgb)[3], XStream& xs) {
+    f32x16 A[8], B[8];
+    float dummy = 0.f;
+    {
+        f32x16 emb[2];
+        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+        pe_pos(px, py, pz, h, emb);
+        u32x4 ehi[6], elo[6];
+        x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+        x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+        if (deform) {
+            f32x16 te;
+            pe_time(ft, h, te);
+            x3_split<false>(te, ehi[4], elo[4], ehi[5], elo[5]);
+            x3_seg<8, 0, 6, SEG_BIAS, TERMS>(A, ehi, elo, xs);
+        } else {
+            x3_seg<8, 0, 4, SEG_BIAS, TERMS>(A, ehi, elo, xs);
+        }
+    }
+    // layer pairs (1,2) (3,4) (5,6) in one loop body, then layer 7; only the canonical net goes on (feature_linear, views)
+#pragma nounroll
+    for (int i = 0; i < 3; ++i) {
+        x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);
+        if (i == 2) {
+            f32x16 emb[2];
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+            pe_pos(px, py, pz, h, emb);
+            u32x4 ehi[4], elo[4];
+            x3_split<false>(emb[0], ehi[0], elo[0], ehi[1], elo[1]);
+            x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
+            x3_seg<8, 0, 4, SEG_ACC, TERMS>(B, ehi, elo, xs);
+        }
+        x3_player<8, TERMS>(A, B, 0.f, nullptr, dummy, 0, xs);
+    }
+    x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);             // layer 7
+    if (deform) {                                                   // dx = _time_out(relu(h_7)): 3 x 8 weight tiles + the head-bias tile
+#pragma nounroll
+        for (int o = 0; o < 3; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = relu1(B[n][r]);
+                s = x3_head_part(t, xs.bias + (o * 8 + n) * SW_BIAS_TILE_FLOATS, s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            s += __shfl_xor(s, 32, 64);
+            const float v = s + xs.bias[24 * SW_BIAS_TILE_FLOATS + o];
+            if (o == 0) head[0] = v; else if (o == 1) head[1] = v; else head[2] = v;
+        }
+        xs.bias += 25 * SW_BIAS_TILE_FLOATS;
+        return;
+    }
+    float hs = 0.f;
+    const float* hw = xs.bias;                                      // alpha_linear rides on the split of h_7 (x3_canon_pipe)
+    const float* hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;
+    x3_player<8, TERMS>(A, B, 0.f, hw, hs, 9, xs);                     // feature_linear
+    hs += __shfl_xor(hs, 32, 64);
+    head[0] = hs + hb[0];
+    f32x16 hv[4];
+    x3_player<4, TERMS>(hv, A, -__builtin_inff(), nullptr, dummy, 0, xs);
+    {
+        f32x16 demb;
+        pe_dir(v0, v1, v2, h, demb);
+        u32x4 dhi[2], dlo[2];
+        x3_split<false>(demb, dhi[0], dlo[0], dhi[1], dlo[1]);
+        x3_seg<4, 0, 2, SEG_ACC, TERMS>(hv, dhi, dlo, xs);
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = relu1(hv[n][r]);
+            s = x3_head_part(t, xs.bias + (o * 4 + n) * SW_BIAS_TILE_FLOATS, s);
+        }
+        rgb[o] = s + __shfl_xor(s, 32, 64) + hb[1 + o];
+    }
+}

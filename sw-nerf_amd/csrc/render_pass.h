@@ -230,7 +230,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             if constexpr (DNERF && PREC != 0) {
 #pragma nounroll
                 for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
+#ifdef X3_NO_PIPE
                     x3_net_dn<PREC>(px, py, pz, ft, pass == 0, h, v0, v1, v2, head, rgb, xs);
+#else
+                    x3_net_dn_pipe<PREC>(px, py, pz, ft, pass == 0, h, v0, v1, v2, head, rgb, xs);
+#endif
                     if (pass == 0) {
                         const float ex = head[0], ey = head[1], ez = head[2];
                         if (a.dx && live && h == 0) {
@@ -284,7 +288,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if constexpr (PREC != 0) {
             head[1] = 0.f; head[2] = 0.f;
+#ifdef X3_NO_PIPE                                   // the plain form (split phase between layers): experiments / reference
             x3_canon<PREC>(px, py, pz, h, lds_dir, lane, head[0], rgb, xs);
+#else
+            x3_canon_pipe<PREC>(px, py, pz, h, lds_dir, lane, head[0], rgb, xs);
+#endif
             x3_rewind(xs, SW_X3_CANON_CHUNKS, lds_bias, lane);
         } else {
             trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);

@@ -115,8 +115,7 @@ def test_weight_gradient_gemm_isa(tmp_path):
 def test_x3_kernels_isa(tmp_path):
     """The bf16x3 / bf16 pass (csrc/mlp_core_x3.h): the properties its shared weight ring relies on.
       * no scratch at all (a scratch reload drains the DMA ring: scratch shares vmcnt),
-      * static MFMA count = groups of the unrolled bodies x terms: L0 (32) + the layer-loop body (128) + its skip part (32)
-        + the view layer (64 + 8) (+ the deformation net's layer 0, 48, in the D-NeRF instantiations),
+      * static MFMA count = groups of the unrolled bodies x terms (the software-pipelined form: a two-layer loop body),
       * one bare s_barrier per chunk of 8 groups (+ the one that publishes chunk 0), each behind a counted vmcnt wait -
         never a `vmcnt(0)` between the first and the last MFMA (it would wait for the whole ring),
       * the refill of a chunk is 4 LDS-DMA instructions, issued one per group."""
@@ -132,9 +131,10 @@ def test_x3_kernels_isa(tmp_path):
             continue
         seen += 1
         terms = 3 if "Li3E" in name else 1
-        groups = 32 + 128 + 32 + 64 + 8
-        if "kernelILb1" in name:                    # D-NeRF: + the deformation net's layer 0 (gamma(x) and gamma(t): 8 x 6)
-            groups += 48
+        # static: L0 (32) + the two-layer loop body (256) + layer 5's gamma(x) part (32) + the view layer (64 + 8)
+        groups = 32 + 256 + 32 + 64 + 8
+        if "kernelILb1" in name:                    # D-NeRF: + the deformation layer 0 (48) + layer 7 and feature_linear outside the loop
+            groups += 48 + 128 + 128
         lines = body.split("\n")
         mf = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
         assert len(mf) == groups * terms, (name, len(mf))
