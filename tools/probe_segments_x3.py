@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Where do the cycles of a bf16x3 tile go?  The fine pass (4096 rays x 192 samples) on a -DSW_PROBE build
-(tools/experiments/probe/build.sh): per wave, shader-clock cycles inside the MFMA segments (weight-ring waits and
-barriers included), the accumulator -> (hi, lo) splits + heads, the gamma(x) evaluations, and the rest of a tile.
-usage: probe_segments_x3.py [bf16x3|bf16]"""
+"""Where do the cycles of a bf16x3 tile go?  The fine pass (4096 rays x 192 samples) on a -DSW_PROBE build:
+  tools/experiments/x3/build.sh probe_plain -DSW_PROBE -DX3_NO_PIPE   the plain form (split phase between layers), stamped inside:
+      MFMA segments (ring waits and barriers included) | accumulator -> (hi, lo) splits + heads | gamma(x) | rest
+  tools/experiments/x3/build.sh probe_pipe -DSW_PROBE                 the shipped software-pipelined form: whole-MLP cycles only
+usage: [SWNERF_LIB=...so] probe_segments_x3.py [bf16x3|bf16]"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +12,7 @@ for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
 import numpy as np
 import torch
 from swnerf import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "experiments", "probe", "libswnerf_probe.so")
+_lib.LIB_PATH = os.path.abspath(os.environ.get("SWNERF_LIB", os.path.join(ROOT, "tools", "experiments", "x3", "libswnerf_probe_plain.so")))
 from swnerf import synth, model, render
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
@@ -44,10 +45,14 @@ seg, split, pe = raw[:, 6] / nt, raw[:, 7] / nt, raw[:, 8] / nt
 print(f"{prec} fine pass, probe build: {ms:.3f} ms per launch (4096 rays x {S} samples; the stamps add their own s_memtime + waits)\n")
 print("| part of a 32-sample tile | cycles (mean over 4096 waves) | note |")
 print("|---|---|---|")
-print(f"| MFMA segments | {seg.mean():,.0f} | ideal {ideal:,} = {groups} groups x {terms} MFMA x 32 cycles; the excess {seg.mean() - ideal:,.0f} is ring waits, barriers, operand reads, bias reads |")
-print(f"| accumulators -> relu -> (hi, lo) + heads | {split.mean():,.0f} | 9 layers |")
-print(f"| gamma(x), twice, + its split | {pe.mean():,.0f} | |")
-print(f"| rest of the MLP call | {(mlp - seg - split - pe).mean():,.0f} | stamps, loop control |")
+stamped = seg.mean() > 0
+if not stamped:
+    print(f"| the MLP call (software-pipelined: no stamps inside) | {mlp.mean():,.0f} | ideal {ideal:,} MFMA cycles |")
+if stamped: print(f"| MFMA segments | {seg.mean():,.0f} | ideal {ideal:,} = {groups} groups x {terms} MFMA x 32 cycles; the excess {seg.mean() - ideal:,.0f} is ring waits, barriers, operand reads, bias reads |")
+if stamped:
+    print(f"| accumulators -> relu -> (hi, lo) + heads | {split.mean():,.0f} | 9 layers |")
+    print(f"| gamma(x), twice, + its split | {pe.mean():,.0f} | |")
+    print(f"| rest of the MLP call | {(mlp - seg - split - pe).mean():,.0f} | stamps, loop control |")
 print(f"| sampling | {front.mean():,.0f} | |")
 print(f"| compositing (+ tile-loop bookkeeping) | {comp.mean():,.0f} | |")
 print(f"| whole tile | {loop.mean():,.0f} | matrix pipe busy if only the MFMAs counted: {100 * ideal / loop.mean():.1f} % |")
