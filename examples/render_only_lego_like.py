@@ -5,6 +5,7 @@ a checkpoint in the reference's `.tar` format (synthetic seeded weights - no tra
 writing '{:03d}.png' frames.  Everything between the checkpoint and the PNGs runs on the fused HIP pass.
 
   python examples/render_only_lego_like.py [out_dir] [H=400] [n_poses=4]
+  SWNERF_PRECISION=bf16x3-fine python examples/render_only_lego_like.py ...     # the opt-in bf16x3 arithmetic
 """
 import os
 import sys
