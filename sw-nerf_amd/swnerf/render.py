@@ -114,6 +114,8 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
 # are then exactly the fp32 path's and the image differs by the MLP rounding alone.
 _PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16x3-fine": 3, "bf16": 1}
 PRECISION = os.environ.get("SWNERF_PRECISION", "fp32")
+if PRECISION not in _PRECISIONS:
+    raise ValueError(f"swnerf: SWNERF_PRECISION={PRECISION!r} is not one of {sorted(_PRECISIONS)}")
 
 
 def set_precision(name):

@@ -231,3 +231,17 @@ def test_get_rays_np_is_the_oracles(built):
     for f in (K, float(K[0, 0])):
         a, b = ray.get_rays_np(20, 30, f, c2w), O.get_rays_np(20, 30, f, c2w)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_precision_switch_is_validated():
+    """render.set_precision / SWNERF_PRECISION accept exactly the documented names (fp32 is the default and the parity path)."""
+    import subprocess
+    import sys
+    import swnerf.render as render
+    assert render.PRECISION == "fp32"
+    with pytest.raises(ValueError):
+        render.set_precision("fp16")
+    assert render.set_precision("bf16x3-fine") == "fp32" and render.set_precision("fp32") == "bf16x3-fine"
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'sw-nerf_amd'); import swnerf.render"],
+                       env=dict(os.environ, SWNERF_PRECISION="tf32"), cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "SWNERF_PRECISION" in r.stderr
