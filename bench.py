@@ -21,6 +21,10 @@ Workloads (BASELINE.json configs / SURVEY.md 8d):
      canonical net per sample, d_nerf/run_dnerf.py:553-566), same sharding.
 fp32 end to end (v_mfma_f32_32x32x2_f32).
 
+--collective always: the N = 1 run joins an RCCL process group of one rank as well (init_process_group("nccl"), the
+all_gather_into_tensor of the pixels on device tensors at the end of every step, the all_reduce(MAX) of the timing) -
+the code path of the N > 1 runs on a box with one GPU.  Default "auto": collectives only when N > 1.
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel - the fine render pass (192 samples/ray) -
 timed with events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle
 (oracle/nerf_oracle.py, kind "port") on the host cores (N = 1 only); `extra.configs` (N = 1 only, measured AFTER and
@@ -53,6 +57,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
+    ap.add_argument("--collective", choices=["auto", "always"], default="auto",
+                    help="always: also at N = 1 join an RCCL group (world 1) and end every step with the real all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs block")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x3-fine"], default="fp32",
@@ -79,15 +85,42 @@ def host_cores():
 
 
 # ------------------------------------------------------------------------------------------- launcher
+def visible_gpu_count(nodes="/sys/class/kfd/kfd/topology/nodes", dri="/dev/dri"):
+    """GPUs this process tree can use, WITHOUT importing torch or touching HIP (the launcher parent must never
+    initialise a GPU: a process that has may not start programs on this pool).  KFD topology nodes with SIMDs whose DRM
+    render node is present and accessible (a container sees every node of the host in sysfs but only its own cards in
+    /dev/dri), then the *_VISIBLE_DEVICES lists."""
+    import glob
+    n = 0
+    have_dri = os.path.isdir(dri)
+    for prop in sorted(glob.glob(os.path.join(nodes, "*", "properties"))):
+        try:
+            kv = dict(l.split(None, 1) for l in open(prop).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(kv.get("simd_count", "0")) <= 0:
+            continue                                     # a CPU node
+        minor = int(kv.get("drm_render_minor", "-1"))
+        if have_dri and minor >= 0 and not os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch(args):
     """--gpus N > 1 without a launcher: become one.  Nothing here may initialise the GPU (a process that has must
-    not start programs on this pool): hipcc through subprocess, torch.cuda.device_count() only (it does not create
-    a context on this image), then N children, each a fresh interpreter."""
+    not start programs on this pool): hipcc through subprocess, the GPU count from sysfs (no torch in this process),
+    then N children, each a fresh interpreter.  The children are polled: the first one that fails takes its siblings
+    down (they would otherwise sit in init_process_group / a collective until the 10-30 min backend timeout) and its
+    exit code becomes the launcher's.  Never re-execs."""
     import __graft_entry__
     __graft_entry__.compile_library()
     rehearsal = os.environ.get("SWNERF_BENCH_REHEARSAL") == "1"
-    import torch
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if have < args.gpus and not rehearsal:
         print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) visible; refusing to report a {args.gpus}-GPU number "
               f"(SWNERF_BENCH_REHEARSAL=1 runs the control flow with ranks sharing cards over gloo)", file=sys.stderr)
@@ -102,9 +135,25 @@ def launch(args):
         # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                print(f"[bench] rank process {procs.index(p)} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()
+                t_kill = time.time() + 15.0
+                while any(q.poll() is None for q in live) and time.time() < t_kill:
+                    time.sleep(0.2)
+                for q in live:
+                    if q.poll() is None:
+                        q.kill()
     return rc
 
 
@@ -202,6 +251,10 @@ def extra_configs(dev):
     rb1 = O.make_ray_batch(torch.from_numpy(o), torch.from_numpy(d), 2., 6.)
     timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50,
            ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"])
+    # the north_star's own target line: lego (nerf/configs/lego.txt: half_res 400x400, N_rand = 1024, 64 + 128, two nets,
+    # white_bkgd, use_viewdirs) - 1024 rays are exactly one wave per SIMD on 256 CUs: both launches run a single round
+    timeit("north_star: lego 1024-ray batch x (64+128), two nets", lambda: render.render(400, 400, K4, rays=r1, **kw), 1024, st["flop_per_ray"], 50,
+           ref=lambda: O.render_rays(rb1, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
     Kf, c2wf = synth.fern_camera()
     o, d = synth.pick_rays(378, 504, Kf, c2wf, N_RAND, 3)
     r3 = (T(o), T(d))
@@ -320,6 +373,11 @@ def extra_configs(dev):
 
 
 def worker(args):
+    # hipcc (subprocesses) strictly BEFORE anything in this process initialises the GPU; under torchrun every rank gets
+    # here, so the compile sits behind a file lock and only the first one in does the work
+    import __graft_entry__
+    __graft_entry__.compile_library_locked()
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -328,25 +386,38 @@ def worker(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: the launcher and the flag disagree")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
     # SWNERF_BENCH_REHEARSAL=1: run the N>1 control flow on a box with fewer GPUs than ranks (ranks share
     # cards, gloo instead of RCCL, pixels staged through the host for the gather).  Not a measurement.
     rehearsal = os.environ.get("SWNERF_BENCH_REHEARSAL") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    ndev = torch.cuda.device_count()                     # counts only: no context yet
+    if ndev == 0 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the render path has no CPU fallback")
+    if local_rank >= ndev and not rehearsal:
+        raise SystemExit(f"[bench] rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible; refusing to share a card "
+                         f"under a {world}-GPU label")
+    dev_index = local_rank % ndev if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    collective = world > 1 or args.collective == "always"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:              # only a bare N = 1 run gets here: nobody else needs the port
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        tmo = datetime.timedelta(seconds=600)
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo, device_id=dev)
+    pr = torch.cuda.get_device_properties(dev)
+    pci = ":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if isinstance(getattr(pr, k, None), int))
+    print(f"[bench] rank {rank}/{world}: cuda:{dev_index} = {pr.name} ({getattr(pr, 'gcnArchName', '?')}, {pr.multi_processor_count} CUs, "
+          f"{pr.total_memory / 2 ** 30:.0f} GiB, pci {pci or '?'}, uuid {getattr(pr, 'uuid', '?')}); "
+          f"collective: {dist.get_backend() if collective else 'none'}", file=sys.stderr, flush=True)
 
-    import __graft_entry__
-    if rank == 0:
-        __graft_entry__.build()
-    if world > 1:
+    __graft_entry__.check_library()                      # symbols only; starts no program
+    if collective:
         dist.barrier()
     from swnerf import synth, render, parallel
     render.set_precision(args.precision)
@@ -368,9 +439,11 @@ def worker(args):
     render.PASS_HOOK = hook
 
     def gather(px):
-        if world > 1 and rehearsal:
-            return parallel.gather_pixels(px.cpu()).to(dev)
-        return parallel.gather_pixels(px) if world > 1 else px
+        if not collective:
+            return px
+        if rehearsal:
+            return parallel.gather_pixels(px.cpu(), force=True).to(dev)
+        return parallel.gather_pixels(px, force=True)    # all_gather_into_tensor on device tensors, also at world 1
 
     if cfg == "C2":
         o_np, d_np = synth.pick_rays(H, W, K, c2w, N_RAND, seed=2 + rank)
@@ -392,7 +465,7 @@ def worker(args):
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -407,7 +480,7 @@ def worker(args):
         fence()
         dt = time.perf_counter() - t0
         hook.on = False
-    if world > 1:
+    if collective:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -439,7 +512,9 @@ def worker(args):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if not x3 else args.precision,
         "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo; not a measurement)" if rehearsal else ""),
-        "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if world > 1 else ""),
+        "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if collective else ""),
+                   "collective": (f"{dist.get_backend()} all_gather_into_tensor of the [n,5] pixels per step + all_reduce(MAX) of the time, world {world}"
+                                  if collective else "none (N = 1)"),
                    "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE,
                    "parallelism": f"ray-sharded dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -498,7 +573,7 @@ def worker(args):
                            "configs": extra_configs(dev)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256) generic_gemm_kernel(GenericGemm P) {
     __shared__ float Bs[64][GK_LD];
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const int wv = t >> 6;
-    const int64_t m0 = (int64_t)blockIdx.y * 64;
-    const int n0 = blockIdx.x * 64;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;     // rows on grid.x (2^31-1 blocks); grid.y is capped at 65535
+    const int n0 = blockIdx.y * 64;
     const int wm = 32 * (wv & 1), wn = 32 * (wv >> 1);
     f32x16 acc;
 #pragma unroll
@@ -94,9 +94,9 @@ static int generic_launch(const GenericGemm& P, bool bt, void* stream, const cha
     if (P.M == 0) return 0;
     if (!P.A || !P.B || !P.C || P.M < 0 || P.N < 1 || P.K < 1 || P.lda < P.K || P.ldc < P.N || P.ldb < (bt ? P.K : P.N))
         return sw_fail(SWNERF_E_ARG, "%s: bad arguments (M=%lld N=%d K=%d lda=%d ldb=%d ldc=%d)", what, (long long)P.M, P.N, P.K, P.lda, P.ldb, P.ldc);
-    const int64_t gy = (P.M + 63) / 64;
-    if (gy > 0x7fffffffLL) return sw_fail(SWNERF_E_UNSUPP, "%s: M too large", what);
-    const dim3 grid((unsigned)((P.N + 63) / 64), (unsigned)gy), block(256);
+    const int64_t gx = (P.M + 63) / 64, gy = (P.N + 63) / 64;
+    if (gx > 0x7fffffffLL || gy > 65535) return sw_fail(SWNERF_E_UNSUPP, "%s: M %lld or N %d too large for one launch", what, (long long)P.M, P.N);
+    const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
     if (bt) hipLaunchKernelGGL(generic_gemm_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(generic_gemm_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), what);

@@ -106,6 +106,7 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (a.n_rays == 0) return 0;
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    pass_startup_args(P, grid.x, a.kind == SWNERF_NET_DNERF && P.two_pass ? SW_DEFORM_STEPS + SW_CANON_STEPS : SW_CANON_STEPS);
     if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
     else {
         // a canonical-only net has no deformation: position_delta is zeros (NeRFOriginal.forward, model.py:273-296

@@ -10,6 +10,7 @@
 // Reference: render_rays nerf/run.py:316-422, d_nerf/run_dnerf.py:354-480; raw2outputs ray.py:155-198;
 // sample_pdf ray.py:96-153; run_network nerf/run.py:73-87.
 #pragma once
+#include <cstdlib>
 #include "mlp_kernels.h"
 #include "mlp_core_x3.h"
 
@@ -31,6 +32,12 @@ struct PassDev {
     float* xs;              // [rows, SW_XS_LD]    the encodings gamma(x), gamma(d) in B-operand SLOT order (sw_xs_col)
     // TRAIN + DNERF: the same three for the deformation net (act_d uses the first 2048 columns; xs_d = gamma(x), gamma(t))
     float* act_d; float* bits_d; float* xs_d;
+    // start-up shaping of a launch (fp32 inference pass; pass_startup() below): L2 warm-up of the weight stream and a skew
+    // of the waves' start.  warm_steps = 0 / skew_mode = 0 switch them off.
+    int warm_steps;         // 1-KiB steps of the weight stream to pull into the XCD's L2 at kernel start
+    int warm_blocks;        // workgroups per XCD that share the warm-up (blocks b with b < 8 * warm_blocks take part)
+    int skew_mode;          // 0 none | 1 per workgroup | 2 per wave
+    int skew_unit;          // s_sleep argument of one skew class (units of 64 clocks)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -84,6 +91,46 @@ __device__ __forceinline__ float z_sample(const swnerf_pass_args& a, int64_t ray
     return lower + (upper - lower) * a.t_rand[ray * S + s];
 }
 
+// ---- start-up shaping ----------------------------------------------------------------------------------------
+// Every launch starts with the weight stream cold in the 8 XCD L2s (they are written back / invalidated at kernel
+// boundaries) and with all resident waves at stream position 0.  The wave that leads takes every L2 miss, the others
+// catch up behind it, and from then on all 128 waves of an XCD ask for the SAME 1-KiB step at the same moment: half of
+// the L2 channels serve all of them while the other half idle.  A launch of many rounds pays that once (about 24 us at
+// 4096 rays), a single-round launch (1024 rays = one wave per SIMD) for its whole duration.  So, before anything else:
+//   warm-up: the first-round waves of an XCD split the stream between them and pull it into L2 with LDS-DMA into a junk
+//            slot (no registers, nothing to wait for except the in-order vmcnt of the ring prime that follows);
+//   skew:    waves (or workgroups) start 0..15 ring steps apart, so that concurrent requests spread over the channels.
+#define SW_WARM_MAX_PER_WAVE 48
+__device__ __forceinline__ void pass_startup(const PassDev& P, const float* w0, float* junk, int lane, int wv) {
+    const unsigned b = blockIdx.x;
+    if (P.warm_steps > 0 && (int)(b >> 3) < P.warm_blocks) {
+        const unsigned junk_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)junk);
+        const int stride = P.warm_blocks * 4;
+        int s = (int)(b >> 3) * 4 + wv;
+#pragma nounroll
+        for (int i = 0; i < SW_WARM_MAX_PER_WAVE && s < P.warm_steps; ++i, s += stride)
+            ws_dma(reinterpret_cast<const char*>(w0) + (size_t)s * 1024, (unsigned)lane * 16u, junk_addr);
+    }
+    if (P.skew_mode) {
+        const int k = (P.skew_mode == 1 ? (int)(b >> 3) : (int)(b >> 3) * 4 + wv) & 15;
+#pragma nounroll
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(4);
+        (void)P.skew_unit;
+    }
+}
+
+// host side: fill the start-up fields for a launch of `grid_x` workgroups whose pass streams `steps` weight steps per tile.
+// SWNERF_WARM / SWNERF_SKEW (experiments: tools/probe_small_batch.py) override the defaults.
+static inline void pass_startup_args(PassDev& P, unsigned grid_x, int steps) {
+    static const int env_warm = [] { const char* e = getenv("SWNERF_WARM"); return e ? atoi(e) : 1; }();
+    static const int env_skew = [] { const char* e = getenv("SWNERF_SKEW"); return e ? atoi(e) : 1; }();
+    const unsigned first_round = grid_x < 256u ? grid_x : 256u;      // one workgroup per CU is resident
+    P.warm_blocks = (int)(first_round / 8u);
+    P.warm_steps = (env_warm && P.warm_blocks > 0) ? steps + SW_TAIL : 0;
+    P.skew_mode = env_skew;
+    P.skew_unit = 4;
+}
+
 // ------------------------------------------------------------------------------------------
 // TRAIN, static net: the LDS bias region holds the canonical tiles alone (the deformation tiles' 11 KB are what lets the
 // 16-deep ring of the training translation unit AND the resampling scratch fit into 160 KB).  TRAIN + DNERF keeps both
@@ -113,6 +160,8 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ray_id = (int64_t)blockIdx.x * 4 + wv;
+    if constexpr (PREC == 0)                     // junk slot = this wave's parked-encoding region: nothing is parked before ws_start's wait
+        pass_startup(P, P.w0, lds_all + PassLds<DNERF, TRAIN>::BIAS + wv * SW_LDS_RING_FLOATS + SW_RING * SW_STEP_FLOATS, lane, wv);
     bias_to_lds(lds_all, P.b0, P.nbias);         // fp32 path: the only block barrier; waves are independent after it
     // PREC: the four waves share the weight ring and run in step, so a wave past the last ray follows along on the
     // last ray and stores nothing
@@ -141,15 +190,23 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const float v0 = rb[a.cols - 3], v1 = rb[a.cols - 2], v2 = rb[a.cols - 1];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
 
-    if (!(PREC && DNERF)) {   // once per ray: the view-direction encoding, parked in LDS (see tile_park)
+    WStream ws;
+    XStream xs;
+    if constexpr (PREC != 0) {
+        if (!DNERF) {         // once per ray: the view-direction encoding, parked in LDS (see tile_park)
+            f32x16 demb;
+            pe_dir(v0, v1, v2, h, demb);
+            tile_park(lds_dir, lane, demb);
+        }
+        x3_start(xs, reinterpret_cast<const char*>(P.w0), lds_bias, lds_ring, lane, wv);
+    } else {
+        // ring prime first (its wait also retires the warm-up DMAs into the junk slot, vmcnt being in order), THEN the
+        // view-direction encoding is parked where the junk went; its ~300 VALU cycles run while steps 1..7 are in flight
+        ws_start(ws, P.w0, lds_bias, lds_ring, lane);
         f32x16 demb;
         pe_dir(v0, v1, v2, h, demb);
         tile_park(lds_dir, lane, demb);
     }
-    WStream ws;
-    XStream xs;
-    if constexpr (PREC != 0) x3_start(xs, reinterpret_cast<const char*>(P.w0), lds_bias, lds_ring, lane, wv);
-    else ws_start(ws, P.w0, lds_bias, lds_ring, lane);
 
     const float* zrow = a.z_vals ? a.z_vals + ray * S : nullptr;
     const float* zslot = PREC ? lds_x3w + X3Lds<DNERF>::DIR : lds_emb + SW_EMB_LDS_FLOATS;

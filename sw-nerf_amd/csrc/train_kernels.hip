@@ -523,6 +523,7 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     if (rc) return rc;
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = nullptr; P.bits_d = nullptr; P.xs_d = nullptr;
     P.sort_n = 0; P.sort_s = 0;
+    P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     size_t lds = PassLds<false, true>::FIXED * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine) return sw_fail(SWNERF_E_ARG, "render_pass_train: n_importance>0 needs z_fine");
@@ -582,6 +583,7 @@ extern "C" int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args, floa
     if (rc) return rc;
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = act_d; P.bits_d = bits_d; P.xs_d = xs_d;
     P.sort_n = 0; P.sort_s = 0;
+    P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     const size_t lds = PassLds<true, true>::FIXED * sizeof(float);
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     hipLaunchKernelGGL((render_pass_kernel<true, true>), grid, block, lds, (hipStream_t)stream, P);

@@ -9,11 +9,16 @@ import torch.distributed as dist
 from .synth import shard_range
 
 
-def gather_pixels(local, counts=None, group=None):
+def gather_pixels(local, counts=None, group=None, force=False):
     """all-gather of per-rank [n_local, C] pixel blocks into [sum n, C] on every rank.
     Equal shards use a single all_gather_into_tensor (one RCCL call); ragged shards pad to the
-    largest and trim."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    largest and trim.  A group of one rank returns `local` without a collective unless `force` (bench.py --collective
+    always: the RCCL call of the N > 1 runs, exercised on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force:
+            raise RuntimeError("swnerf.parallel.gather_pixels(force=True) needs an initialised process group")
+        return local
+    if dist.get_world_size(group) == 1 and not force:
         return local
     world = dist.get_world_size(group)
     n, c = local.shape
@@ -82,26 +87,26 @@ def allreduce_gradients(modules, group=None, average=True):
         return
     dev, dt = params[0].device, params[0].dtype
     n = sum(p.numel() for p in params)
-    flat = torch.zeros(n + len(params), dtype=dt, device=dev)    # tail: one "has a gradient" flag per parameter
-    off = 0
-    for i, p in enumerate(params):
-        k = p.numel()
-        if p.grad is not None:
-            flat[off:off + k].copy_(p.grad.reshape(-1))
-            flat[n + i] = 1.0
-        off += k
+    # ONE bucket: every gradient (zeros for a parameter this rank has none for) followed by one "has a gradient" flag per
+    # parameter.  The flags are built on the host and uploaded as one small tensor; the bucket is one torch.cat - no
+    # per-parameter launches beyond the views cat reads from.
+    has_local = [p.grad is not None for p in params]
+    pieces = [(p.grad if h else torch.zeros_like(p)).reshape(-1).to(dt) for p, h in zip(params, has_local)]
+    pieces.append(torch.tensor([1.0 if h else 0.0 for h in has_local], dtype=dt).to(dev, non_blocking=True))
+    flat = torch.cat(pieces)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     world = dist.get_world_size(group)
     if average:
         flat[:n] /= world
-    has = flat[n:].tolist()                                      # (one small D2H; the step ends with optimizer.step anyway)
-    off = 0
-    for i, p in enumerate(params):
-        k = p.numel()
-        if has[i] > 0:
-            g = flat[off:off + k].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-        off += k
+    if all(has_local):
+        has = has_local                                          # every rank sums >= 1 there: no read-back needed
+    else:
+        has = [v > 0 for v in flat[n:].tolist()]                 # the rare case (a D-NeRF rank at t == 0): one small D2H
+    grads = torch.split(flat[:n], [p.numel() for p in params])
+    for p, g, h in zip(params, grads, has):
+        if not h:
+            continue
+        if p.grad is None:
+            p.grad = g.view_as(p).clone()
+        else:
+            p.grad.copy_(g.view_as(p))

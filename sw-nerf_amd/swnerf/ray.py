@@ -81,6 +81,26 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     return o, d
 
 
+SAMPLE_PDF_MAX_BINS = 1024          # csrc/misc_kernels.hip SP_MAX_BINS: the kernel keeps a ray's cdf in LDS
+
+
+def _sample_pdf_wide(bins, weights, N_samples, u):
+    """More bins than the kernel's LDS slice holds (N_samples > 1025 coarse samples; the reference takes any count,
+    ray.py:96-153), or the degenerate single bin: the same inverse-CDF arithmetic as device tensor ops."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    if u is None:
+        u = torch.linspace(0., 1., steps=N_samples, device=bins.device).expand(bins.shape[0], N_samples)
+    idx = torch.searchsorted(cdf, u.contiguous(), right=True)
+    lo, hi = (idx - 1).clamp_min(0), idx.clamp_max(cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
+
+
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
     """ray.py:96-153.  `u` (extra, optional) injects the uniforms instead of torch.rand."""
     bins = _lib.dev_f32(bins, "bins")
@@ -95,6 +115,8 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
         u = None if det else torch.Tensor(np.random.rand(N, N_samples)).to(bins.device)
     if u is not None:
         u = _lib.dev_f32(u, "u", N_samples)
+    if nb < 2 or nb > SAMPLE_PDF_MAX_BINS:
+        return _sample_pdf_wide(bins, weights, int(N_samples), u)
     samples = torch.empty((N, N_samples), dtype=torch.float32, device=bins.device)
     _lib.check(_lib.lib().swnerf_sample_pdf(_lib.ptr(bins), _lib.ptr(weights), N, nb, int(N_samples), _lib.ptr(u),
                                             _lib.ptr(samples), None, 0, None, None, _lib.stream_of(bins)), "sample_pdf")

@@ -287,6 +287,35 @@ def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, 
     return out
 
 
+PASS_MAX_COARSE, PASS_MAX_SORT = 256, 1024   # csrc/render_pass.h SW_LDS_SC / SW_LDS_SORT: the in-LDS resampling of swnerf_render_pass
+
+
+def pass_can_resample(N_samples, N_importance):
+    """Whether the fused coarse pass can do the hierarchical resampling of these counts in its LDS slice."""
+    return 3 <= N_samples <= PASS_MAX_COARSE and N_samples + N_importance <= PASS_MAX_SORT
+
+
+def resample_ops(z_vals, weights, N_importance, u=None):
+    """nerf/run.py:394-400,416 on the individual ops, for sample counts beyond the fused pass's LDS slice (the reference
+    takes any N_samples): sample_pdf on the mid-points (the HIP op; device tensor ops past 1024 bins), torch.sort of
+    cat[z_vals, z_samples], std of the samples.  u None = deterministic (perturb == 0).  -> z_fine [N, S+Ni], z_std [N]"""
+    z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(u is None), u=u).detach()
+    z_fine, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
+    return z_fine.contiguous(), torch.std(z_samples, dim=-1, unbiased=False)
+
+
+def coarse_pass_resampled(ray_batch, net, N_samples, N_importance, *, want, u=None, **kw):
+    """The coarse pass + resampling of render_rays: ONE fused launch when the counts fit its LDS slice, otherwise the
+    fused pass without resampling (weights and depths written out) followed by resample_ops.  Returns render_pass's dict
+    with z_fine / z_std either way."""
+    if pass_can_resample(N_samples, N_importance):
+        return render_pass(ray_batch, net, N_samples, want=want, n_importance=N_importance, u=u, **kw)
+    p0 = render_pass(ray_batch, net, N_samples, want=list(want) + ["weights", "z_out"], **kw)
+    p0["z_fine"], p0["z_std"] = resample_ops(p0["z_out"], p0["weights"], N_importance, u)
+    return p0
+
+
 TRAIN_FUSED_MAX_SAMPLES = 256      # include/swnerf.h: swnerf_render_pass_train
 TRAIN_BWD_CHUNK_ROWS = 393216      # rows of the gradient buffer alive at once in the fused backward (3.8 GB); each chunk costs one
                                    # atomic epilogue per GEMM (~44 us), so not smaller than needed
@@ -351,13 +380,15 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         ret.update({'rgb0': p0["rgb_map"], 'disp0': p0["disp_map"], 'acc0': p0["acc_map"], 'z_std': p0["z_std"]})
         return ret
     want = ["rgb_map", "disp_map", "acc_map"] + (["raw"] if (retraw and N_importance <= 0) else [])
-    p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
-                     white_bkgd=white_bkgd, want=want, n_importance=max(0, N_importance), u=u)
     if N_importance <= 0:
+        p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
+                         white_bkgd=white_bkgd, want=want)
         ret = {'rgb_map': p0["rgb_map"], 'disp_map': p0["disp_map"], 'acc_map': p0["acc_map"]}
         if retraw:
             ret['raw'] = p0["raw"]
         return ret
+    p0 = coarse_pass_resampled(ray_batch, network_fn, N_samples, N_importance, want=want, u=u, lindisp=lindisp, t_rand=t_rand,
+                               noise=noise(N_samples), white_bkgd=white_bkgd)
     S1 = N_samples + N_importance
     run_fn = network_fn if network_fine is None else network_fine
     p1 = render_pass(ray_batch, run_fn, S1, z_vals=p0["z_fine"], noise=noise(S1), white_bkgd=white_bkgd,

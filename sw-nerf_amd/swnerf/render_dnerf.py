@@ -1,6 +1,7 @@
 """Counterparts of the render functions of the reference's D-NeRF runner
 (d_nerf/run_dnerf.py:24-235, 354-480): batchify, run_network, batchify_rays, render,
 render_rays with the frame_time plumbing.  Same fused dispatch as swnerf.render."""
+import contextvars
 import os
 
 import numpy as np
@@ -10,7 +11,7 @@ from . import _lib
 from .embedder import to8b
 from .png import write_png
 from .ray import get_rays, sample_pdf, raw2outputs
-from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coarse_z
+from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coarse_z, coarse_pass_resampled
 from .model import DirectTemporalNeRF
 
 DEBUG = False
@@ -56,13 +57,15 @@ def run_network(inputs, viewdirs, frame_time, fn, embed_fn, embeddirs_fn, embedt
 # frame_time known on the host (render() was handed a Python float, the normal case: d_nerf/run_dnerf.py:208,667 pass
 # one time per frame): keyed by the ray batch's storage, valid only while render() runs, so that render_rays - whose
 # signature is the reference's and carries the time only as column 8 - needs no device->host sync per chunk.
-_TIME_HINT = {}
+# A context variable (per thread / task, restored on exit - nested or concurrent render() calls cannot read each other's
+# time) holding (storage address of the ray batch render() built, the time AS THE KERNELS READ IT: rounded to float32).
+_TIME_HINT = contextvars.ContextVar("swnerf_frame_time_hint", default=None)
 
 
 def _single_time(ray_batch):
-    hint = _TIME_HINT.get(ray_batch.untyped_storage().data_ptr())
-    if hint is not None:
-        return hint
+    hint = _TIME_HINT.get()
+    if hint is not None and hint[0] == ray_batch.untyped_storage().data_ptr():
+        return hint[1]
     lo, hi = torch.aminmax(ray_batch[:, 8])
     lo, hi = float(lo), float(hi)
     assert lo == hi, "Only accepts all points from same time"      # run_dnerf.py:53
@@ -271,9 +274,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             z_final = p1["z_out"]
         else:
             want0 = ["rgb_map", "disp_map", "acc_map", "dx"] if use_two_models_for_fine else []
-            p0 = render_pass(ray_batch, network_fn, N_samples, lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples),
-                             white_bkgd=white_bkgd, want=want0, n_importance=N_importance, u=u,
-                             run_deform=deform(network_fn))
+            p0 = coarse_pass_resampled(ray_batch, network_fn, N_samples, N_importance, want=want0, u=u, lindisp=lindisp,
+                                       t_rand=t_rand, noise=noise(N_samples), white_bkgd=white_bkgd, run_deform=deform(network_fn))
             z_final, z_std = p0["z_fine"], p0["z_std"]
             p1 = None
     else:
@@ -315,9 +317,9 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
                 t0 = _single_time(ray_batch)
                 deform = isinstance(network_fn, DirectTemporalNeRF) and not (t0 == 0. and network_fn.zero_canonical)
                 t_rand, u, noise = _rng_inputs(N_rays, N_samples, N_importance, perturb, raw_noise_std, pytest, ray_batch.device)
-                fused_coarse = render_pass(ray_batch.detach(), network_fn, N_samples, lindisp=lindisp, t_rand=t_rand,
-                                           noise=noise(N_samples), white_bkgd=white_bkgd, want=[], n_importance=N_importance,
-                                           u=u, run_deform=deform)
+                fused_coarse = coarse_pass_resampled(ray_batch.detach(), network_fn, N_samples, N_importance, want=[], u=u,
+                                                     lindisp=lindisp, t_rand=t_rand, noise=noise(N_samples), white_bkgd=white_bkgd,
+                                                     run_deform=deform)
     z_std = None
     if fused_coarse is not None:
         z_vals, z_std = fused_coarse["z_fine"], fused_coarse["z_std"]
@@ -380,13 +382,13 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         rb[:, -3:] = pack_ray_batch(rays_o, viewsrc, near, far)[:, -3:]
     if not use_viewdirs:
         rb = rb[:, :9].contiguous()          # rays = cat[o, d, near, far, frame_time] (run_dnerf.py:153-159)
-    key = rb.untyped_storage().data_ptr()
-    if isinstance(ft, float):
-        _TIME_HINT[key] = ft
+    # the hint carries float32(frame_time): a double that is non-zero but rounds to 0.0f must pick the t == 0 branch on the
+    # host exactly as the device sees it in column 8
+    token = _TIME_HINT.set((rb.untyped_storage().data_ptr(), float(np.float32(ft))) if isinstance(ft, float) else None)
     try:
         all_ret = batchify_rays(rb, chunk, **kwargs)
     finally:
-        _TIME_HINT.pop(key, None)
+        _TIME_HINT.reset(token)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']

@@ -34,6 +34,34 @@ def test_bench_spawns_its_own_ranks():
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_rccl_leg_at_world_1():
+    """The code path the driver's N > 1 runs hit first, on the one GPU this box has: `bench.py --collective always` joins an
+    RCCL group of ONE rank (init_process_group("nccl", device_id=...)), every step ends with all_gather_into_tensor on the
+    DEVICE tensor of the pixels and the timing goes through all_reduce(MAX).  The number must agree with the
+    no-collective N = 1 run (the gather of 80 KB is latency only) - that is also the "N = 1 of SCALE agrees with BENCH"
+    check.  Both runs are fresh child processes, started before this process has touched the GPU."""
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: starting programs from it is not allowed on this pool")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SWNERF_BENCH_REHEARSAL")}
+    lines = {}
+    for mode in ("always", "auto"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--collective", mode, "--steps", "30", "--warmup", "5",
+                            "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        if mode == "always":
+            assert "collective: nccl" in r.stderr and "rank 0/1: cuda:0 = " in r.stderr, r.stderr[-2000:]
+    a, b = lines["always"], lines["auto"]
+    assert a["n_gpus"] == 1 and "nccl all_gather_into_tensor" in a["config"]["collective"] and "RCCL all-gather" in a["config"]["workload"]
+    assert b["config"]["collective"].startswith("none")
+    print(f"[rccl world 1] with collective {a['value']:.0f} rays/s ({a['ms_per_step']:.3f} ms/step), without {b['value']:.0f} rays/s "
+          f"({b['ms_per_step']:.3f} ms/step): ratio {a['value'] / b['value']:.4f}")
+    assert 0.98 < a["value"] / b["value"] < 1.02, (a["value"], b["value"])
+    assert abs(a["roofline"]["frac"] - b["roofline"]["frac"]) < 0.01
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """No launcher, --gpus 2, fewer GPUs than ranks and no rehearsal flag: exit non-zero, no JSON (never a 1-GPU number
     under an N-GPU label).  Runs anywhere: the launcher parent touches no GPU."""

@@ -95,3 +95,56 @@ def test_sharded_render_gloo_world2():
     assert np.array_equal(same[:5], np.zeros((5, 3))) and np.array_equal(same[5:], np.ones((5, 3)))
     assert rag.shape == (7, 2) and np.array_equal(rag[:3], np.zeros((3, 2))) and np.array_equal(rag[3:], np.ones((4, 2)))
     assert tmax == 2.0 and grads_ok
+
+
+def test_gather_pixels_force_runs_the_collective_at_world_1():
+    """bench.py --collective always: a group of ONE rank still goes through all_gather_into_tensor (gloo here, RCCL on
+    the GPU box) instead of the early return - and without a process group `force` is an error, not a silent no-op."""
+    for p in (ROOT, os.path.join(ROOT, "sw-nerf_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from swnerf import parallel
+    a = torch.arange(15, dtype=torch.float32).reshape(5, 3)
+    assert parallel.gather_pixels(a) is a
+    with pytest.raises(RuntimeError):
+        parallel.gather_pixels(a, force=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda out, inp, group=None: (calls.append(1), real(out, inp, group=group))[1]
+        try:
+            assert parallel.gather_pixels(a) is a and not calls                 # default: no collective for one rank
+            g = parallel.gather_pixels(a, force=True)
+        finally:
+            dist.all_gather_into_tensor = real
+        assert calls == [1] and g is not a and torch.equal(g, a)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_launcher_counts_gpus_from_sysfs_without_torch(tmp_path, monkeypatch):
+    """bench.py's launcher parent counts GPUs from the KFD topology (+ accessible render nodes + *_VISIBLE_DEVICES) so that
+    it never imports torch or touches HIP before it starts the rank processes."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, -1), (1024, 128), (1024, 129), (1024, 130)]):     # a CPU node and three GPUs
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for m in (128, 129):                                                                     # the container may open two of them
+        (dri / f"renderD{m}").write_text("")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count(str(nodes), str(dri)) == 2
+    assert bench.visible_gpu_count(str(nodes), str(tmp_path / "no_dri")) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(nodes), str(dri)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count(str(nodes), str(dri)) == 0
+    assert bench.visible_gpu_count(str(tmp_path / "nothing"), str(dri)) == 0
+    import inspect
+    src = inspect.getsource(bench.launch) + inspect.getsource(bench.visible_gpu_count)
+    assert "import torch" not in src and "torch." not in src

@@ -56,6 +56,16 @@ def test_linear_kernel_shapes(dev):
         ref = ref.clamp_min(0) if relu else ref
         assert y.shape == (M, N)
         close(y, ref.float(), atol=2e-5, rtol=1e-5, what=f"linear M={M} K={K} N={N}")
+    # more than 65536 row blocks (rows sit on grid.x: grid.y stops at 65535 blocks = 4.19 M rows): run_network with netchunk=None
+    # on a full frame reaches this
+    M = 65536 * 64 + 77
+    lin = torch.nn.Linear(8, 4).to(dev)
+    x = torch.randn((M, 8), device=dev)
+    with torch.no_grad():
+        y = generic.linear(x, lin, relu=False)
+        for sl in (slice(0, 64), slice(M - 200, M)):
+            close(y[sl], (x[sl].double() @ lin.weight.double().T + lin.bias.double()).float(), atol=2e-5, what="linear, M > 65536 x 64")
+    del x, y
     # autograd of one layer: dX, dW, db vs torch
     lin = torch.nn.Linear(90, 37).to(dev)
     x = T(rng.standard_normal((211, 90)).astype(np.float32)).to(dev).requires_grad_(True)

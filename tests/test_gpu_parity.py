@@ -507,6 +507,31 @@ def test_render_rays_ragged_and_edges(sw, dev, nets):
     assert none["rgb_map"].shape == (0, 3) and none["z_std"].shape == (0,)
 
 
+def test_render_rays_beyond_the_lds_slice(sw, dev, nets):
+    """The reference takes any N_samples / N_importance (nerf/run.py:361-400).  The fused coarse pass resamples in an LDS
+    slice of 256 coarse / 1024 merged depths; beyond that render_rays must NOT fail (round-2 VERDICT: SWNERF_E_UNSUPP
+    surfaced as a RuntimeError) but run the fused pass without resampling + sample_pdf / sort as ops + the fused fine pass."""
+    q = _query(sw)
+    sd_c, sd_f = (O.to_torch_sd(s) for s in cases.weights_static())
+    g = cases.g7_inputs(n=256, seed=41)
+    assert not sw.render.pass_can_resample(300, 64) and not sw.render.pass_can_resample(64, 1000) and sw.render.pass_can_resample(256, 768)
+    for (S, Ni) in ((300, 64), (64, 1000), (257, 0)):
+        r = sw.render.render_rays(_rb(g, dev), nets["coarse"], q, S, N_importance=Ni, network_fine=nets["fine"], white_bkgd=True, retraw=True)
+        ref = O.render_rays(_rb(g, "cpu"), sd_c, sd_f, S, Ni, white_bkgd=True, retraw=True)
+        assert r["raw"].shape == (256, S + Ni, 4)
+        keys = [k for k in r.keys() if k != "raw"]
+        _cmp(r, ref, keys, f"beyond LDS S={S} Ni={Ni}", resampled=Ni > 0, frac_min=0.85, psnr_min=65.0)
+    # the same through the D-NeRF runner's render_rays (t = 0: the canonical net alone, well conditioned)
+    qd = _query_d(sw)
+    gd = cases.g8_inputs()
+    rb = _rb(gd, dev, 0.0)[:128]
+    r = sw.render_dnerf.render_rays(rb, nets["dn"], qd, 300, N_importance=64, white_bkgd=True)
+    ref = O.render_rays_dnerf(rb.cpu(), O.to_torch_sd(cases.weights_dnerf()), 300, 64, white_bkgd=True)
+    assert r["z_vals"].shape == (128, 364)
+    close_mostly(r["rgb_map"], ref["rgb_map"], atol=2e-4, frac=0.85, hard=2e-2, what="dnerf beyond LDS rgb")
+    close(r["z_std"], ref["z_std"], atol=2e-3, what="dnerf beyond LDS z_std")
+
+
 # -------------------------------------------------------------- render_rays (d_nerf/run_dnerf.py)
 def _query_d(sw):
     embed_fn, _ = sw.embedder.get_embedder(10, 3, 0)

@@ -68,7 +68,9 @@ def test_mfma_kernels_isa(asm):
         # ring priming: 8 steps in the render unit, 16 in the training unit (train_kernels.hip)
         training = any(k in name for k in ("mlp_backward_dx", "deform_", "mlp_forward_kernelILb0ELb1E", "render_pass_backward",
                                            "render_pass_kernelILb0ELb1E", "render_pass_kernelILb1ELb1E"))
-        assert dma == steps + (16 if training else 8) + masks, (name, dma)
+        # the fused pass pulls the weight stream into L2 at kernel start with one more static DMA site (render_pass.h pass_startup)
+        warm = 1 if "render_pass_kernel" in name else 0
+        assert dma == steps + (16 if training else 8) + masks + warm, (name, dma)
     assert len(seen) == 14
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)
