@@ -220,11 +220,22 @@ def extra_configs(dev):
 
     def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False, ref=None):
         """ref: None, or callable(first 256 rows of fn()'s rgb on the GPU) -> the CPU oracle's rgb for the same rays
-        (the checker, outside the timed region): PSNR of the HIP render against it goes into the row."""
+        (the checker, outside the timed region): PSNR of the HIP render against it goes into the row.
+        Untimed warm-up: at least two calls AND 0.25 s of them - after the seconds of GPU idle that every row's CPU-oracle
+        check leaves behind, the first ~2 ms of GPU work run at a reduced clock (measured round 3,
+        profiles/r03/clock_ramp.md: the same 1024-ray launch 578 us as the first thing timed, 536 us after others), which a
+        50 x 0.57 ms row would otherwise carry as 8 % of its time.  The timed region is >= 0.1 s."""
         ctx = torch.enable_grad() if grad else torch.no_grad()
         with ctx:
             out = fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
             fn()
+            torch.cuda.synchronize(dev)
+            one = max(time.perf_counter() - t0, 1e-5)
+            for _ in range(int(0.25 / one)):
+                fn()
+            reps = max(reps, int(0.1 / one) + 1)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -255,6 +266,31 @@ def extra_configs(dev):
     # white_bkgd, use_viewdirs) - 1024 rays are exactly one wave per SIMD on 256 CUs: both launches run a single round
     timeit("north_star: lego 1024-ray batch x (64+128), two nets", lambda: render.render(400, 400, K4, rays=r1, **kw), 1024, st["flop_per_ray"], 50,
            ref=lambda: O.render_rays(rb1, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+    # use_viewdirs=False - the reference's argparse default (utils.py:43, model.py:59-60, 8-column rays nerf/run.py:152-157):
+    # the C2 batch through two nets WITHOUT the view branch (output_ch = 5), on the fused pass's own variant; FLOPs per row
+    # = 2 x (63*256 + 4*256^2 + 319*256 + 2*256^2 + 256*5) = 984 576
+    from swnerf import model, embedder
+    e_fn, in_ch = embedder.get_embedder(10, 3, 0)
+    nv = []
+    for seed, ab in ((20250321, -0.25), (20250322, -1.0)):
+        m = model.vallina_NeRF(D=8, W=256, input_ch=in_ch, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+        sd_np = synth.noview_state_dict(seed, alpha_bias=ab)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        nv.append((m.to(dev).eval(), O.to_torch_sd(sd_np)))
+    embed_fn, embeddirs_fn = e_fn, None
+    q_nv = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+    o2, d2 = synth.pick_rays(800, 800, K8, c2w8, N_RAND, 2)
+    r2 = (T(o2), T(d2))
+    kw_nv = dict(kw, use_viewdirs=False, network_fn=nv[0][0], network_fine=nv[1][0], network_query_fn=q_nv)
+    flop_nv = 2 * (63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * 5)
+
+    def ref_nv():
+        # the oracle's one-net render twice over: coarse net for the depths, fine net on them (nerf/run.py:394-413)
+        rb = O.make_ray_batch(torch.from_numpy(o2[:256]), torch.from_numpy(d2[:256]), 2., 6.)[:, :8]
+        mlp = lambda sd_: (lambda e: O.generic_mlp(sd_, e, 8, [4], 63, 0, False))
+        return O.render_rays_two_nets_generic(rb, mlp(nv[0][1]), mlp(nv[1][1]), N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"]
+    timeit("C2 shape with use_viewdirs=False (the reference's default): 4096 x (64+128), two 8x256 nets without the view branch, fused",
+           lambda: render.render(800, 800, K8, rays=r2, **kw_nv), N_RAND, (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * flop_nv, 10, ref=ref_nv)
     Kf, c2wf = synth.fern_camera()
     o, d = synth.pick_rays(378, 504, Kf, c2wf, N_RAND, 3)
     r3 = (T(o), T(d))
@@ -469,7 +505,15 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    PREWARM_S = 0.25
     with torch.no_grad():
+        # clock pre-warm (untimed, before the W warm-up steps, reported as config.clock_prewarm_s): the scene set-up above is
+        # seconds of GPU idle, and the first milliseconds of GPU work after an idle spell run at a reduced clock
+        # (profiles/r03/clock_ramp.md); W = 5 steps of 8 ms do not reliably cover that
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PREWARM_S:
+            step()
+            torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             step()
         fence()
@@ -515,7 +559,7 @@ def worker(args):
         "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if collective else ""),
                    "collective": (f"{dist.get_backend()} all_gather_into_tensor of the [n,5] pixels per step + all_reduce(MAX) of the time, world {world}"
                                   if collective else "none (N = 1)"),
-                   "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE,
+                   "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE, "clock_prewarm_s": PREWARM_S,
                    "parallelism": f"ray-sharded dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,

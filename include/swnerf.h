@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 103
+#define SWNERF_VERSION 104
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -33,6 +33,8 @@ extern "C" {
 /* packed-network kinds (swnerf_packed_floats / swnerf_pack_*) */
 #define SWNERF_NET_CANON   0     /* vallina_NeRF == NeRFOriginal: 8x256, skip@4, view branch */
 #define SWNERF_NET_DNERF   1     /* DirectTemporalNeRF: deformation net then canonical net   */
+#define SWNERF_NET_NOVIEW  2     /* vallina_NeRF with use_viewdirs=False (the reference's argparse default, utils.py:43;
+                                    model.py:59-60): 8x256, skip@4, outputs = output_linear(h), 4 or 5 channels */
 
 int         swnerf_version(void);
 const char* swnerf_last_error(void);
@@ -55,6 +57,11 @@ const char* swnerf_last_error(void);
 size_t swnerf_packed_floats(int kind);
 int swnerf_pack_net(int kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
                     int L_time, float* packed, void* stream);
+/* SWNERF_NET_NOVIEW (model.py:22-37 with use_viewdirs=False): params =
+ *   [0..15]  pts_linears.{0..7}.{weight,bias}
+ *   [16,17]  output_linear.{weight,bias}        [out_ch,256], out_ch = 4 or 5 (nerf/run.py:231)
+ * packed: swnerf_packed_floats(SWNERF_NET_NOVIEW) floats. */
+int swnerf_pack_net_noview(const float* const* params /*HOST*/, int L_pos, int out_ch, float* packed, void* stream);
 
 /* ---- ray.py -------------------------------------------------------------------------- */
 
@@ -200,10 +207,11 @@ int swnerf_sample_coarse(const float* ray_batch, int64_t n_rays, int cols, int n
  * for pts / embeddings / activations / raw. */
 typedef struct swnerf_pass_args {
     /* inputs */
-    const float* ray_batch;   /* [N, cols]  cols = 11, or 12 with frame_time at column 8 */
+    const float* ray_batch;   /* [N, cols]  cols = 11, or 12 with frame_time at column 8; SWNERF_NET_NOVIEW: 8 = [o, d, near, far]
+                                 (rays without view directions, nerf/run.py:152-157) */
     int64_t      n_rays;
     int          cols;
-    int          kind;        /* SWNERF_NET_CANON / SWNERF_NET_DNERF */
+    int          kind;        /* SWNERF_NET_CANON / SWNERF_NET_DNERF / SWNERF_NET_NOVIEW */
     const float* packed;      /* packed net of that kind */
     int          run_deform;  /* DNERF only: 0 = `t==0 and zero_canonical` branch */
     int          L_pos, L_dir, L_time;
@@ -221,7 +229,7 @@ typedef struct swnerf_pass_args {
     float* depth_map;         /* [N]   */
     /* per-sample outputs, any may be NULL */
     float* weights;           /* [N,S]   */
-    float* raw;               /* [N,S,4] */
+    float* raw;               /* [N,S,4]  (SWNERF_NET_NOVIEW: [N,S,out_ch]) */
     float* dx;                /* [N,S,3] position_delta (DNERF) */
     float* z_out;             /* [N,S]   the depths this pass sampled */
     /* hierarchical resampling after compositing (nerf/run.py:394-400), n_importance==0: off */
@@ -229,6 +237,7 @@ typedef struct swnerf_pass_args {
     const float* u;           /* NULL: det (perturb==0); else [N,n_importance] uniforms */
     float* z_fine;            /* [N, S+n_importance] sorted union */
     float* z_std;             /* [N] std of the new samples, may be NULL */
+    int          out_ch;      /* SWNERF_NET_NOVIEW: channels of output_linear (4 or 5); ignored otherwise */
 } swnerf_pass_args;
 
 int swnerf_render_pass(const swnerf_pass_args* args /*HOST*/, void* stream);

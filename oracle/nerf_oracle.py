@@ -362,7 +362,7 @@ def generic_dnerf_mlp(sd, x, t_emb, D, skips, input_ch, input_ch_views, use_view
     return generic_mlp(sd, torch.cat([pts, views], -1), D, skips, input_ch, input_ch_views, use_viewdirs, prefix="_occ."), dx
 
 
-def render_rays_generic(ray_batch, net_fn, N_samples, N_importance=0, white_bkgd=False, multires=10, multires_views=4):
+def render_rays_generic(ray_batch, net_fn, N_samples, N_importance=0, white_bkgd=False, multires=10, multires_views=4, retraw=False):
     """render_rays (nerf/run.py:316-422) with ONE net given as a callable embedded-rows -> raw (any output_ch >= 4), with or
     without view directions (ray_batch 11 or 8 columns), perturb = 0."""
     N = ray_batch.shape[0]
@@ -389,4 +389,31 @@ def render_rays_generic(ray_batch, net_fn, N_samples, N_importance=0, white_bkgd
         rgb, disp, acc, w, _ = raw2outputs(raw[..., :4], z, rays_d, 0., white_bkgd)
         ret["z_std"] = torch.std(zs, dim=-1, unbiased=False)
     ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc)
+    if retraw:
+        ret["raw"] = raw
     return ret
+
+
+def render_rays_two_nets_generic(ray_batch, coarse_fn, fine_fn, N_samples, N_importance, white_bkgd=False, multires=10, multires_views=4):
+    """render_rays (nerf/run.py:316-422) with separate coarse and fine nets given as callables embedded-rows -> raw (any
+    output_ch >= 4), with or without view directions (ray_batch 11 or 8 columns), perturb = 0, N_importance > 0."""
+    N = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+
+    def query(net_fn, pts):
+        e = embed(pts.reshape(-1, 3), multires)
+        if viewdirs is not None:
+            e = torch.cat([e, embed(viewdirs[:, None].expand(pts.shape).reshape(-1, 3), multires_views)], -1)
+        raw = net_fn(e)
+        return raw.reshape(N, -1, raw.shape[-1])
+
+    z = coarse_z(near, far, N_samples)
+    raw = query(coarse_fn, rays_o[:, None] + rays_d[:, None] * z[..., None])
+    rgb0, disp0, acc0, w, _ = raw2outputs(raw[..., :4], z, rays_d, 0., white_bkgd)
+    zs = sample_pdf(.5 * (z[:, 1:] + z[:, :-1]), w[:, 1:-1], N_importance, det=True)
+    z, _ = torch.sort(torch.cat([z, zs], -1), -1)
+    raw = query(fine_fn, rays_o[:, None] + rays_d[:, None] * z[..., None])
+    rgb, disp, acc, w, _ = raw2outputs(raw[..., :4], z, rays_d, 0., white_bkgd)
+    return dict(rgb_map=rgb, disp_map=disp, acc_map=acc, rgb0=rgb0, disp0=disp0, acc0=acc0, z_std=torch.std(zs, dim=-1, unbiased=False), z_vals=z)

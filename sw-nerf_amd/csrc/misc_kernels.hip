@@ -11,7 +11,8 @@ char* sw_errbuf() { return g_err; }
 extern "C" const char* swnerf_last_error(void) { return g_err; }
 extern "C" int swnerf_version(void) { return SWNERF_VERSION; }
 extern "C" size_t swnerf_packed_floats(int kind) {
-    return kind == SWNERF_NET_CANON ? (size_t)SW_CANON_FLOATS : (kind == SWNERF_NET_DNERF ? (size_t)SW_DNERF_FLOATS : 0);
+    return kind == SWNERF_NET_CANON ? (size_t)SW_CANON_FLOATS
+         : (kind == SWNERF_NET_DNERF ? (size_t)SW_DNERF_FLOATS : (kind == SWNERF_NET_NOVIEW ? (size_t)SW_NOVIEW_FLOATS : 0));
 }
 
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }

@@ -264,6 +264,29 @@ __device__ __forceinline__ void head_valu(const f32x16 (&x)[NT], WStream& ws, fl
     ws.bias += NOUT * NT * SW_BIAS_TILE_FLOATS;
 }
 
+// The same with a run-time output count (output_linear of a net without view directions: 4 or 5 channels):
+// res[o] for o < nout, untouched beyond.  One loop body (256 FMAs per lane), not nout unrolled copies.
+template <int NT>
+__device__ __forceinline__ void head_valu_rt(const f32x16 (&x)[NT], WStream& ws, int nout, float (&res)[5]) {
+#pragma nounroll
+    for (int o = 0; o < nout; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(ws.bias + (o * NT + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                acc = fmaf(w[0], x[n][4 * g + 0], acc); acc = fmaf(w[1], x[n][4 * g + 1], acc);
+                acc = fmaf(w[2], x[n][4 * g + 2], acc); acc = fmaf(w[3], x[n][4 * g + 3], acc);
+            }
+        float v = acc + __shfl_xor(acc, 32, 64);
+        asm volatile("" : "+v"(v));
+        res[0] = o == 0 ? v : res[0]; res[1] = o == 1 ? v : res[1]; res[2] = o == 2 ? v : res[2];
+        res[3] = o == 3 ? v : res[3]; res[4] = o == 4 ? v : res[4];
+    }
+    ws.bias += nout * NT * SW_BIAS_TILE_FLOATS;
+}
+
 // ---- activation tiles -> a row of a row-major [M, ld] buffer (training path) ---------------------
 // register r = 4g+e of lane (j,h) of tile n is feature 32n + 8g + 4h + e of row j: 16 contiguous bytes.
 // rowp = base + row*ld + 4h.  (Lanes past M use row M-1: they carry copies of that row, the stores are benign.)
@@ -364,7 +387,9 @@ __device__ __forceinline__ void tile_fetch(const float* lds_tile, int lane, f32x
 // segment here: store_last writes it on the spot, otherwise the caller side-stores it (in `in`, mask in *mb).
 // XS (fused training pass): the two position-encoding k-tiles go to xs_row (+ 4h; slot order, sw_xs_col) as side
 // stores of layer 0, whose B operand they are.
-template <bool DNERF, bool TRAIN = false, bool XS = false>
+// NOHEAD: stop after layer 7 (`in` = relu(h7)); the caller applies its own head (output_linear of a net without view
+// directions, head_valu_rt).
+template <bool DNERF, bool TRAIN = false, bool XS = false, bool NOHEAD = false>
 __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_emb, float t, bool deform_pass, int h,
                                            f32x16 (&in)[8], f32x16 (&out)[8], float (&head)[3], WStream& ws,
                                            float* act_row = nullptr, float* mask_tile = nullptr, bool store_last = false,
@@ -413,6 +438,7 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
             *mb = mbits;
         }
     }
+    if constexpr (NOHEAD) return;
     // head biases: one tile right behind the weight tiles, the same 16 floats in both lane halves:
     // [b_alpha, b_r, b_g, b_b] (canonical) / [b_dx0, b_dx1, b_dx2] (deformation)
     if (DNERF && deform_pass) {

@@ -112,3 +112,11 @@ static inline int stream_ptrs(int kind, const float* packed, int run_deform, con
     return 0;
 }
 
+// SWNERF_NET_NOVIEW: stream and bias tiles of the net without view directions (swnerf_pack_net_noview)
+static inline int stream_ptrs_noview(const float* packed, int out_ch, const float** w0, const float** b0, int* nbias, int* two) {
+    if (out_ch < 4 || out_ch > SW_NOVIEW_MAX_OUT) return sw_fail(SWNERF_E_UNSUPP, "net without view directions: out_ch %d (4 or 5)", out_ch);
+    *w0 = packed; *b0 = packed + SW_NOVIEW_W_FLOATS; *two = 0;
+    *nbias = SW_NOVIEW_BIAS_TILES(out_ch) * SW_BIAS_TILE_FLOATS;
+    return 0;
+}
+

@@ -199,6 +199,22 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     return tail(vl.w, packed + SW_CANON_VL_OFFSET);
 }
 
+// use_viewdirs=False (model.py:59-60): the trunk alone; output_linear's rows ride as bias-style tiles like the other heads.
+extern "C" int swnerf_pack_net_noview(const float* const* params, int L_pos, int out_ch, float* packed, void* stream) {
+    if (!params || !packed) return sw_fail(SWNERF_E_ARG, "pack_net_noview: NULL pointer");
+    if (L_pos < 0 || L_pos > 10) return sw_fail(SWNERF_E_UNSUPP, "pack_net_noview: %d position bands exceed 10", L_pos);
+    if (out_ch < 4 || out_ch > SW_NOVIEW_MAX_OUT)
+        return sw_fail(SWNERF_E_UNSUPP, "pack_net_noview: output_ch %d (the reference builds 4 or 5, nerf/run.py:231)", out_ch);
+    for (int i = 0; i < 18; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_noview: params[%d] is NULL", i);
+    hipStream_t st = (hipStream_t)stream;
+    Packer pk{st, packed, packed + SW_NOVIEW_W_FLOATS, L_pos, 0, 0, 0};
+    pk.trunk(params, params[16], params[17], out_ch, 3 * (1 + 2 * L_pos), 0);
+    if (pk.rc) return pk.rc;
+    if (pk.w != packed + (size_t)SW_NOVIEW_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(out_ch) * SW_BIAS_TILE_FLOATS)
+        return sw_fail(SWNERF_E_ARG, "pack_net_noview: internal layout mismatch");
+    return sw_check(hipMemcpyAsync(pk.w, packed, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_noview tail copy");
+}
+
 // The backward (dX chain) streams: transposed weights in the order the backward kernels consume them
 // (swnerf_common.h SW_BWD_* / SW_DBWD_*), then the head weights as bias-style tiles.
 extern "C" size_t swnerf_packed_bwd_floats_kind(int bwd_kind) {

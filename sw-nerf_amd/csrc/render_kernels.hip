@@ -80,14 +80,18 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     const swnerf_pass_args& a = *args;
     if (!a.packed || (!a.ray_batch && a.n_rays != 0)) return sw_fail(SWNERF_E_ARG, "render_pass: NULL ray_batch/packed");
     if (a.n_rays < 0 || a.n_samples < 2) return sw_fail(SWNERF_E_ARG, "render_pass: n_rays %lld, n_samples %d", (long long)a.n_rays, a.n_samples);
-    if (a.cols != 11 && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: ray_batch must have 11 or 12 columns (use_viewdirs), got %d", a.cols);
+    const bool noview = a.kind == SWNERF_NET_NOVIEW;
+    if (noview ? a.cols != 8 : (a.cols != 11 && a.cols != 12))
+        return sw_fail(SWNERF_E_ARG, "render_pass: ray_batch must have 11 or 12 columns (use_viewdirs) or 8 (SWNERF_NET_NOVIEW), got %d for kind %d", a.cols, a.kind);
     if (a.kind == SWNERF_NET_DNERF && a.cols != 12) return sw_fail(SWNERF_E_ARG, "render_pass: D-NeRF needs the frame_time column");
+    if (noview && a.dx) return sw_fail(SWNERF_E_ARG, "render_pass: a static net has no position_delta output here");
     if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4 || a.L_time < 0 || a.L_time > 10)
         return sw_fail(SWNERF_E_UNSUPP, "render_pass: embedder bands (%d,%d,%d) exceed (10,4,10)", a.L_pos, a.L_dir, a.L_time);
     if (a.z_vals && a.t_rand) return sw_fail(SWNERF_E_ARG, "render_pass: t_rand only applies to coarse sampling");
     PassDev P;
     P.a = a;
-    int rc = stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
+    int rc = noview ? stream_ptrs_noview(a.packed, a.out_ch, &P.w0, &P.b0, &P.nbias, &P.two_pass)
+                    : stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
     P.sort_n = 0; P.sort_s = 0;
     size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
@@ -106,8 +110,9 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (a.n_rays == 0) return 0;
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    pass_startup_args(P, grid.x, a.kind == SWNERF_NET_DNERF && P.two_pass ? SW_DEFORM_STEPS + SW_CANON_STEPS : SW_CANON_STEPS);
-    if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
+    pass_startup_args(P, grid.x, noview ? SW_NOVIEW_STEPS : (a.kind == SWNERF_NET_DNERF && P.two_pass ? SW_DEFORM_STEPS + SW_CANON_STEPS : SW_CANON_STEPS));
+    if (noview) hipLaunchKernelGGL((render_pass_kernel<false, false, 0, false>), grid, block, lds, st, P);
+    else if (a.kind == SWNERF_NET_DNERF) hipLaunchKernelGGL(render_pass_kernel<true>, grid, block, lds, st, P);
     else {
         // a canonical-only net has no deformation: position_delta is zeros (NeRFOriginal.forward, model.py:273-296
         // returns torch.zeros_like(input_pts[:, :3])); the static kernel has no dx store, so fill it here

@@ -151,9 +151,12 @@ template <bool DNERF> struct X3Lds {
 };
 
 // PREC: 0 = fp32 MFMA (mlp_core.h, the parity path); 3 = bf16x3, 1 = plain bf16 (mlp_core_x3.h; static net, inference)
-template <bool DNERF, bool TRAIN = false, int PREC = 0>
+// VIEWS = false: the net without view directions (SWNERF_NET_NOVIEW; model.py:59-60, 8-column ray batch nerf/run.py:152-157):
+// the trunk, then output_linear as VALU heads - no feature / view branch, no gamma(d).  Static net, fp32, inference.
+template <bool DNERF, bool TRAIN = false, int PREC = 0, bool VIEWS = true>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     static_assert(PREC == 0 || !TRAIN, "the bf16 paths cover the inference passes");
+    static_assert(VIEWS || (!DNERF && !TRAIN && PREC == 0), "the no-view-direction variant is the static fp32 inference pass");
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     SW_STAMP(probe_start);
     const swnerf_pass_args& a = P.a;
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     const float ox = rb[0], oy = rb[1], oz = rb[2], dx = rb[3], dy = rb[4], dz = rb[5];
     const float near = rb[6], far = rb[7];
     const float ft = (a.cols == 12) ? rb[8] : 0.f;
-    const float v0 = rb[a.cols - 3], v1 = rb[a.cols - 2], v2 = rb[a.cols - 1];
+    const float v0 = VIEWS ? rb[a.cols - 3] : 0.f, v1 = VIEWS ? rb[a.cols - 2] : 0.f, v2 = VIEWS ? rb[a.cols - 1] : 0.f;
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);                  // ray.py:173
 
     WStream ws;
@@ -203,9 +206,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         // ring prime first (its wait also retires the warm-up DMAs into the junk slot, vmcnt being in order), THEN the
         // view-direction encoding is parked where the junk went; its ~300 VALU cycles run while steps 1..7 are in flight
         ws_start(ws, P.w0, lds_bias, lds_ring, lane);
-        f32x16 demb;
-        pe_dir(v0, v1, v2, h, demb);
-        tile_park(lds_dir, lane, demb);
+        if constexpr (VIEWS) {
+            f32x16 demb;
+            pe_dir(v0, v1, v2, h, demb);
+            tile_park(lds_dir, lane, demb);
+        }
     }
 
     const float* zrow = a.z_vals ? a.z_vals + ray * S : nullptr;
@@ -244,6 +249,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
 
         f32x16 emb[2], in[8], out[8];
         float head[3], rgb[3];
+        float extra = 0.f;                          // VIEWS = false, out_ch == 5: the fifth channel of output_linear (only `raw` shows it)
         pe_pos(px, py, pz, h, emb);
         SW_STAMP(pt1);
         if (DNERF && TRAIN) {
@@ -351,11 +357,19 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             x3_canon_pipe<PREC>(px, py, pz, h, lds_dir, lane, head[0], rgb, xs);
 #endif
             x3_rewind(xs, SW_X3_CANON_CHUNKS, lds_bias, lane);
+        } else if constexpr (!VIEWS) {
+            trunk_pass<false, false, false, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
+            // outputs = output_linear(h) (model.py:59-60): [rgb(3), sigma, (5th, unused by raw2outputs)]
+            float o5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            head_valu_rt<8>(in, ws, a.out_ch, o5);
+            rgb[0] = o5[0] + ws.bias[0]; rgb[1] = o5[1] + ws.bias[1]; rgb[2] = o5[2] + ws.bias[2];
+            head[0] = o5[3] + ws.bias[3]; head[1] = 0.f; head[2] = 0.f;
+            extra = o5[4] + ws.bias[4];
         } else {
             trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
         }
         SW_STAMP(pt2);
-        if (!TRAIN && PREC == 0) {
+        if (!TRAIN && PREC == 0 && VIEWS) {
             f32x16 demb;
             tile_fetch(lds_dir, lane, demb);
             canon_tail(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
@@ -367,8 +381,13 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         const float c0 = rgb[0], c1 = rgb[1], c2 = rgb[2];
         float sg = head[0];
         if (a.raw && live && h == 0) {
-            f32x4 r4 = {c0, c1, c2, sg};
-            *reinterpret_cast<f32x4*>(a.raw + (ray * S + s) * 4) = r4;
+            if (!VIEWS && a.out_ch == 5) {
+                float* o = a.raw + (ray * S + s) * 5;
+                o[0] = c0; o[1] = c1; o[2] = c2; o[3] = sg; o[4] = extra;
+            } else {
+                f32x4 r4 = {c0, c1, c2, sg};
+                *reinterpret_cast<f32x4*>(a.raw + (ray * S + s) * 4) = r4;
+            }
         }
         if (a.noise) sg += a.noise[ray * S + sc];
         float dist = (s + 1 < S) ? (zn - z) : 1e10f;

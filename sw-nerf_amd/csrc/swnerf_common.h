@@ -40,6 +40,15 @@
 #define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
 #define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 24 + 1)
 
+// net WITHOUT view directions (use_viewdirs=False, model.py:59-60: outputs = output_linear(h)), 8x256, skip@4:
+// stream L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 = 1920 steps; bias tiles: 64 | output_linear.weight out_ch x 8 | 1 tile of
+// output_linear.bias.  out_ch = 4 or 5 (nerf/run.py:231: 5 when N_importance > 0; raw2outputs reads channels 0..3).
+#define SW_NOVIEW_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
+#define SW_NOVIEW_MAX_OUT 5
+#define SW_NOVIEW_BIAS_TILES(out_ch) (64 + 8 * (out_ch) + 1)
+#define SW_NOVIEW_W_FLOATS ((SW_NOVIEW_STEPS + SW_TAIL) * SW_STEP_FLOATS)
+#define SW_NOVIEW_FLOATS (SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(SW_NOVIEW_MAX_OUT) * SW_BIAS_TILE_FLOATS)
+
 // blob CANON : [canon steps][ring tail = copy of first SW_TAIL steps][canon bias][views loop]
 // views loop  : [VIEWS steps][tail = copy of the first SW_TAIL VIEWS steps] - the view
 //               branch as a stream that wraps onto itself, for queries of many view directions per

@@ -8,9 +8,9 @@ from ctypes import c_int, c_int64, c_double, c_void_p, c_size_t, c_char_p, POINT
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libswnerf_hip.so")
 
-NET_CANON, NET_DNERF = 0, 1
+NET_CANON, NET_DNERF, NET_NOVIEW = 0, 1, 2
 
-EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net",
+EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net", "swnerf_pack_net_noview",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_sample_coarse", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
@@ -35,6 +35,7 @@ class PassArgs(Structure):
         ("rgb_map", c_void_p), ("disp_map", c_void_p), ("acc_map", c_void_p), ("depth_map", c_void_p),
         ("weights", c_void_p), ("raw", c_void_p), ("dx", c_void_p), ("z_out", c_void_p),
         ("n_importance", c_int), ("u", c_void_p), ("z_fine", c_void_p), ("z_std", c_void_p),
+        ("out_ch", c_int),
     ]
 
 
@@ -59,6 +60,7 @@ def lib():
     L.swnerf_packed_floats.restype = c_size_t
     L.swnerf_packed_floats.argtypes = [c_int]
     L.swnerf_pack_net.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_pack_net_noview.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
     L.swnerf_get_rays.argtypes = [c_int, c_int, c_double, c_double, c_double, c_double, c_int,
                                   POINTER(ctypes.c_float), c_int64, c_int64, c_void_p, c_void_p, c_void_p]
     L.swnerf_ndc_rays.argtypes = [c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int64,
@@ -120,8 +122,8 @@ def lib():
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
                         "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 103:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 103 - rebuild it "
+    if L.swnerf_version() != 104:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 104 - rebuild it "
                            "(python __graft_entry__.py)")
     _lib = L
     return L

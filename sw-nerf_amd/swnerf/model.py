@@ -25,6 +25,8 @@ from .embedder import img2mse, mse2psnr, to8b  # noqa: F401
 _CANON_ORDER = ([f"pts_linears.{i}.{p}" for i in range(8) for p in ("weight", "bias")]
                 + [f"{n}.{p}" for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear")
                    for p in ("weight", "bias")])
+_NOVIEW_ORDER = ([f"pts_linears.{i}.{p}" for i in range(8) for p in ("weight", "bias")]
+                 + [f"output_linear.{p}" for p in ("weight", "bias")])
 _DEFORM_ORDER = ([f"_time.{i}.{p}" for i in range(8) for p in ("weight", "bias")]
                  + [f"_time_out.{p}" for p in ("weight", "bias")])
 
@@ -359,6 +361,35 @@ class _PackedMixin:
 
     def _pack_params(self):
         raise NotImplementedError
+
+    def _noview_params(self):
+        """(names, L_pos, out_ch) when this is the 8x256 / skips=[4] net WITHOUT view directions (use_viewdirs=False, the
+        reference's argparse default: model.py:59-60, outputs = output_linear(h) with 4 or 5 channels, nerf/run.py:231) -
+        the shape the fused render pass has a variant for (SWNERF_NET_NOVIEW); else None."""
+        if not (self.D == 8 and self.W == 256 and list(self.skips) == [4] and not self.use_viewdirs and hasattr(self, "output_linear")):
+            return None
+        Lp = _bands(self.input_ch, 3)
+        out_ch = self.output_linear.out_features
+        if Lp is None or Lp > 10 or out_ch not in (4, 5):
+            return None
+        return _NOVIEW_ORDER, Lp, out_ch
+
+    def packed_noview(self):
+        """(packed float tensor of kind SWNERF_NET_NOVIEW, L_pos, out_ch), cached like packed()."""
+        names, Lp, out_ch = self._noview_params()
+        sd = dict(self.named_parameters())
+        ps = [sd[n] for n in names]
+        if not ps[0].is_cuda:
+            raise RuntimeError("swnerf: module parameters must be on the GPU (call .to('cuda')); no CPU fallback")
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._pack_key:
+            L = _lib.lib()
+            ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
+            arr = (ctypes.c_void_p * len(ps32))(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_floats(_lib.NET_NOVIEW), dtype=torch.float32, device=ps[0].device)
+            _lib.check(L.swnerf_pack_net_noview(arr, Lp, out_ch, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_noview")
+            self._packed, self._pack_key = buf, key
+        return self._packed, Lp, out_ch
 
     def packed(self):
         """(kind, packed float tensor, L_pos, L_dir, L_time)"""

@@ -79,6 +79,12 @@ def wants_grad(nets):
     return torch.is_grad_enabled() and any(p.requires_grad for net in nets if isinstance(net, torch.nn.Module) for p in net.parameters())
 
 
+def nets_without_views(nets):
+    """True when every net given is the 8x256 net WITHOUT view directions the fused pass has a variant for."""
+    real = [net for net in nets if net is not None]
+    return bool(real) and all(isinstance(net, vallina_NeRF) and net._noview_params() is not None for net in real)
+
+
 def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
     """Returns (L_pos, L_dir, L_time) when every net is a swnerf module on the GPU and the
     closure's encoders are the standard ones matching the nets' input sizes; else None.
@@ -88,7 +94,16 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
         return None
     emb = closure_embedders(network_query_fn)
     ef, edf, etf = emb.get("embed_fn"), emb.get("embeddirs_fn"), emb.get("embedtime_fn")
-    if not (isinstance(ef, EmbedFn) and isinstance(edf, EmbedFn) and ef.input_dims == 3 and edf.input_dims == 3):
+    if not (isinstance(ef, EmbedFn) and ef.input_dims == 3):
+        return None
+    real = [net for net in nets if net is not None]
+    if nets_without_views(nets):
+        # use_viewdirs=False (the reference's argparse default): no direction encoder exists (nerf/run.py:227-229 leaves
+        # embeddirs_fn None), rays have 8 columns; the fused pass has a variant without the view branch.  Inference only.
+        if need_time or wants_grad(nets) or any(net.input_ch != ef.out_dim for net in real):
+            return None
+        return ef.multires, 0, 0
+    if not (isinstance(edf, EmbedFn) and edf.input_dims == 3):
         return None
     if need_time and not (isinstance(etf, EmbedFn) and etf.input_dims == 1):
         return None
@@ -132,24 +147,31 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
     """One launch of `swnerf_render_pass` (include/swnerf.h).  Returns a dict of the requested
     outputs among rgb_map disp_map acc_map depth_map weights raw dx z_out, plus z_fine/z_std
     when n_importance > 0.  precision: None = the module setting (PRECISION)."""
-    kind, packed, Lp, Ld, Lt = net.packed()
-    mode = PRECISION if precision is None else precision
-    terms = _PRECISIONS[mode]
-    if mode == "bf16x3-fine" and n_importance > 0:
-        terms = 0
-    if terms:
-        packed, _, _ = net.packed_x3()
+    noview = isinstance(net, vallina_NeRF) and net._noview_params() is not None
+    out_ch = 4
+    if noview:                                           # the fp32 pass without the view branch (SWNERF_NET_NOVIEW)
+        packed, Lp, out_ch = net.packed_noview()
+        kind, Ld, Lt, terms = _lib.NET_NOVIEW, 0, 0, 0
+    else:
+        kind, packed, Lp, Ld, Lt = net.packed()
+        mode = PRECISION if precision is None else precision
+        terms = _PRECISIONS[mode]
+        if mode == "bf16x3-fine" and n_importance > 0:
+            terms = 0
+        if terms:
+            packed, _, _ = net.packed_x3()
     rb = _lib.dev_f32(ray_batch, "ray_batch")
     N, cols = rb.shape
     S = int(n_samples)
     dev = rb.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     shapes = {"rgb_map": (N, 3), "disp_map": (N,), "acc_map": (N,), "depth_map": (N,), "weights": (N, S),
-              "raw": (N, S, 4), "dx": (N, S, 3), "z_out": (N, S)}
+              "raw": (N, S, out_ch), "dx": (N, S, 3), "z_out": (N, S)}
     out = {k: new(*shapes[k]) for k in want}
     a = _lib.PassArgs()
     a.ray_batch, a.n_rays, a.cols, a.kind, a.packed = rb.data_ptr(), N, cols, kind, packed.data_ptr()
     a.run_deform, a.L_pos, a.L_dir, a.L_time, a.n_samples = int(bool(run_deform)), Lp, Ld, Lt, S
+    a.out_ch = out_ch
     keep = [rb, packed]
     for name, t, last in (("z_vals", z_vals, S), ("t_rand", t_rand, S), ("noise", noise, S), ("u", u, int(n_importance))):
         if t is not None:
@@ -348,7 +370,9 @@ def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev)
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False):
     """nerf/run.py:316-422."""
-    plan = fused_plan(network_query_fn, [network_fn, network_fine], allow_train=True) if ray_batch.shape[-1] == 11 else None
+    plan = fused_plan(network_query_fn, [network_fn, network_fine], allow_train=True) if ray_batch.shape[-1] in (8, 11) else None
+    if plan is not None and nets_without_views([network_fn, network_fine]) != (ray_batch.shape[-1] == 8):
+        plan = None                                      # 8 columns <=> nets without view directions
     training = wants_grad([network_fn, network_fine])
     if plan is not None and training:
         # the fused pass has a backward for the static nets, up to 256 samples per pass; anything else trains on the

@@ -55,6 +55,25 @@ def nerf_state_dict(seed, input_ch=63, input_ch_views=27, alpha_bias=-0.35, pref
     return sd
 
 
+def noview_state_dict(seed, input_ch=63, output_ch=5, alpha_bias=-0.35, bias_scale=0.05):
+    """Weights of one vallina_NeRF with use_viewdirs=False (model.py:22-37, 59-60; the reference's argparse default):
+    the 8 trunk layers, the (unused) views_linears.0 that the module still owns, and output_linear [output_ch, 256] whose
+    channel 3 (the density) gets the opacity-centring bias."""
+    rng = np.random.default_rng(seed)
+    W = WIDTH
+    sd = {}
+    ins = [input_ch] + [W + input_ch if i == 4 else W for i in range(D_LAYERS - 1)]
+    for i, k in enumerate(ins):
+        sd[f"pts_linears.{i}.weight"] = _he(rng, W, k)
+        sd[f"pts_linears.{i}.bias"] = (rng.standard_normal(W) * bias_scale).astype(np.float32)
+    sd["views_linears.0.weight"] = _he(rng, W // 2, W)
+    sd["views_linears.0.bias"] = (rng.standard_normal(W // 2) * bias_scale).astype(np.float32)
+    sd["output_linear.weight"] = _he(rng, output_ch, W)
+    sd["output_linear.bias"] = (rng.standard_normal(output_ch) * bias_scale).astype(np.float32)
+    sd["output_linear.bias"][3] = alpha_bias
+    return sd
+
+
 def dnerf_state_dict(seed, input_ch=63, input_ch_views=27, input_ch_time=21, alpha_bias=-0.35,
                      dx_scale=0.05, bias_scale=0.05):
     """Weights of one DirectTemporalNeRF: canonical `_occ.*` plus deformation net."""

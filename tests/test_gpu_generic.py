@@ -116,6 +116,8 @@ def test_render_without_viewdirs_golden(dev, golden):
                                                                 embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
     r = g["rays"]
     K, _ = cases.synth.lego_camera(400, 400)
+    # round 3: this shape has a FUSED pass of its own (SWNERF_NET_NOVIEW) - the closure and the net qualify for it
+    assert render.fused_plan(q, [net, None]) == (10, 0, 0) and render.nets_without_views([net, None])
     with torch.no_grad():
         rgb, disp, acc, extras = render.render(400, 400, K, rays=(T(r["rays_o"]).to(dev), T(r["rays_d"]).to(dev)), ndc=False, near=2., far=6.,
                                                use_viewdirs=False, network_fn=net, network_query_fn=q, N_samples=32, N_importance=32,
@@ -126,6 +128,59 @@ def test_render_without_viewdirs_golden(dev, golden):
     d = (rgb.cpu() - T(ref["rr_rgb_map"])).abs()
     assert float((d <= 2e-4).float().mean()) >= 0.9 and float(d.max()) <= 2e-2, f"rgb_map: within 2e-4 {float((d <= 2e-4).float().mean()):.3f}, max {float(d.max()):.2e}"
     close(extras["z_std"], ref["rr_z_std"], atol=2e-3, what="z_std")
+
+
+def test_fused_pass_without_viewdirs_vs_oracle(dev):
+    """The fused render pass for use_viewdirs=False (csrc/render_pass.h VIEWS = false: trunk + output_linear as VALU heads,
+    8-column rays; model.py:59-60, nerf/run.py:152-157) against the CPU oracle: coarse-only with the 5-channel raw, the
+    hierarchical 64+128 case, and against the layer-by-layer generic path it replaces (same module, opaque closure)."""
+    import swnerf.embedder as embedder, swnerf.render as render
+    kw = cases.G11_NETS["novd"]
+    net = _net(dev, "novd").eval()
+    sd = O.to_torch_sd(cases.g11_weights("novd"))
+    net_fn = lambda e: O.generic_mlp(sd, e, kw["D"], kw["skips"], kw["input_ch"], 0, False)
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn = None
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    g = cases.g7_inputs(n=301, seed=57)                          # not a multiple of 4: a partly filled last workgroup
+    rb8 = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), g["near"], g["far"])[:, :8].contiguous()
+    with torch.no_grad():
+        r = render.render_rays(rb8.to(dev), net, q, 64, retraw=True, N_importance=0, white_bkgd=True)
+        ref = O.render_rays_generic(rb8, net_fn, 64, 0, white_bkgd=True, retraw=True)
+        assert r["raw"].shape == (301, 64, 5)
+        close(r["raw"], ref["raw"], atol=1e-3, rtol=1e-4, what="raw, 5 channels")
+        close(r["rgb_map"], ref["rgb_map"], atol=2e-5, what="rgb coarse only")
+        close(r["acc_map"], ref["acc_map"], atol=2e-5, what="acc coarse only")
+        close(r["disp_map"], ref["disp_map"], atol=2e-5, rtol=1e-4, what="disp coarse only")
+        for S, Ni in ((64, 128), (40, 24)):
+            r = render.render_rays(rb8.to(dev), net, q, S, retraw=True, N_importance=Ni, network_fine=None, white_bkgd=True)
+            ref = O.render_rays_generic(rb8, net_fn, S, Ni, white_bkgd=True)
+            assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"] and r["raw"].shape == (301, S + Ni, 5)
+            close(r["rgb0"], ref["rgb0"], atol=2e-5, what="rgb0")
+            close(r["acc0"], ref["acc0"], atol=2e-5, what="acc0")
+            close(r["z_std"], ref["z_std"], atol=2e-3, what="z_std")
+            d = (r["rgb_map"].cpu() - ref["rgb_map"]).abs()
+            db = float(-10 * torch.log10(((r["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean()))
+            print(f"\n[parity] no-viewdirs fused S={S} Ni={Ni}: within 2e-4 {float((d <= 2e-4).float().mean()):.4f}, max {float(d.max()):.2e}, PSNR {db:.1f} dB")
+            assert float((d <= 2e-4).float().mean()) >= 0.92 and float(d.max()) <= 2e-2 and db >= 70.0
+        # the generic layer-by-layer path (an opaque closure hides the encoder, so no fused plan) gives the same image
+        opaque = lambda a, b, c, _q=q: _q(a, b, c)
+        assert render.fused_plan(opaque, [net, None]) is None
+        a = render.render_rays(rb8.to(dev), net, q, 64, N_importance=0, white_bkgd=True, retraw=True)
+        b = render.render_rays(rb8.to(dev), net, opaque, 64, N_importance=0, white_bkgd=True, retraw=True)
+        close(a["raw"], b["raw"], atol=2e-4, rtol=1e-4, what="fused vs generic raw")
+        close(a["rgb_map"], b["rgb_map"], atol=2e-5, what="fused vs generic rgb")
+        # 4-channel head, empty batch, and the wrong column count is an error of the C ABI, not a wrong image
+        net4 = __import__("swnerf.model", fromlist=["x"]).vallina_NeRF(**dict(kw, output_ch=4)).to(dev).eval()
+        r4 = render.render_rays(rb8.to(dev)[:9], net4, q, 64, retraw=True, white_bkgd=False)
+        assert r4["raw"].shape == (9, 64, 4) and bool(torch.isfinite(r4["rgb_map"]).all())
+        sd4 = {k: v.detach().cpu() for k, v in net4.state_dict().items()}
+        ref4 = O.render_rays_generic(rb8[:9], lambda e: O.generic_mlp(sd4, e, 8, [4], 63, 0, False), 64, 0, white_bkgd=False, retraw=True)
+        close(r4["raw"], ref4["raw"], atol=1e-3, rtol=1e-4, what="raw, 4 channels")
+        assert render.render_rays(rb8.to(dev)[:0], net, q, 64, N_importance=16)["rgb_map"].shape == (0, 3)
+        with pytest.raises(RuntimeError):
+            render.render_pass(torch.zeros((4, 11), device=dev), net, 64)
 
 
 def test_generic_training_matches_autograd(dev):
