@@ -272,7 +272,7 @@ def extra_configs(dev):
     from swnerf import model, embedder
     e_fn, in_ch = embedder.get_embedder(10, 3, 0)
     nv = []
-    for seed, ab in ((20250321, -0.25), (20250322, -1.0)):
+    for seed, ab in ((20250321, 0.5), (20250322, 0.7)):          # opacity biases tuned with the CPU oracle (acc spans 0.2..1.0)
         m = model.vallina_NeRF(D=8, W=256, input_ch=in_ch, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
         sd_np = synth.noview_state_dict(seed, alpha_bias=ab)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})

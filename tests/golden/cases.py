@@ -247,3 +247,17 @@ def g11_inputs(n=300):
     dirs = rng.standard_normal((n, 3)).astype(np.float32)
     dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
     return dict(pts=pts, dirs=dirs.astype(np.float32), rays=g7_inputs(n=64, seed=111))
+
+
+# ------------------------------------------------------------------ G12 render_rays without view directions, non-degenerate weights
+G12_NET = dict(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+
+
+def g12_weights():
+    """(coarse, fine) nets of the shape `--use_viewdirs` unset gives (nerf/run.py:226-231); opacity biases tuned with the CPU
+    oracle so that acc spans (0.2, 1.0) / (0.1, 1.0) on the G12 rays."""
+    return synth.noview_state_dict(20250321, alpha_bias=0.5), synth.noview_state_dict(20250322, alpha_bias=0.7)
+
+
+def g12_inputs(n=256):
+    return g7_inputs(n=n, seed=57)

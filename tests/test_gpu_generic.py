@@ -117,8 +117,8 @@ def test_render_without_viewdirs_golden(dev, golden):
     r = g["rays"]
     K, _ = cases.synth.lego_camera(400, 400)
     # round 3: this shape has a FUSED pass of its own (SWNERF_NET_NOVIEW) - the closure and the net qualify for it
-    assert render.fused_plan(q, [net, None]) == (10, 0, 0) and render.nets_without_views([net, None])
     with torch.no_grad():
+        assert render.fused_plan(q, [net, None]) == (10, 0, 0) and render.nets_without_views([net, None])
         rgb, disp, acc, extras = render.render(400, 400, K, rays=(T(r["rays_o"]).to(dev), T(r["rays_d"]).to(dev)), ndc=False, near=2., far=6.,
                                                use_viewdirs=False, network_fn=net, network_query_fn=q, N_samples=32, N_importance=32,
                                                network_fine=None, white_bkgd=True, perturb=0., raw_noise_std=0.)
@@ -130,57 +130,73 @@ def test_render_without_viewdirs_golden(dev, golden):
     close(extras["z_std"], ref["rr_z_std"], atol=2e-3, what="z_std")
 
 
-def test_fused_pass_without_viewdirs_vs_oracle(dev):
+def test_fused_pass_without_viewdirs_golden(dev, golden):
     """The fused render pass for use_viewdirs=False (csrc/render_pass.h VIEWS = false: trunk + output_linear as VALU heads,
-    8-column rays; model.py:59-60, nerf/run.py:152-157) against the CPU oracle: coarse-only with the 5-channel raw, the
-    hierarchical 64+128 case, and against the layer-by-layer generic path it replaces (same module, opaque closure)."""
-    import swnerf.embedder as embedder, swnerf.render as render
-    kw = cases.G11_NETS["novd"]
-    net = _net(dev, "novd").eval()
-    sd = O.to_torch_sd(cases.g11_weights("novd"))
-    net_fn = lambda e: O.generic_mlp(sd, e, kw["D"], kw["skips"], kw["input_ch"], 0, False)
+    8-column rays; model.py:59-60, nerf/run.py:152-157) against the REFERENCE's own render_rays on non-degenerate weights
+    (golden G12, tests/golden/make_golden_noview.py): coarse-only with the 5-channel raw, the hierarchical 64+128 case with
+    two nets; then against the CPU oracle at ragged sizes, and against the layer-by-layer generic path it replaces."""
+    import swnerf.embedder as embedder, swnerf.render as render, swnerf.model as model
+    ref, g = golden("g12_noview"), cases.g12_inputs()
+    nets, sds = [], []
+    for sd_np in cases.g12_weights():
+        m = model.vallina_NeRF(**cases.G12_NET)
+        m.load_state_dict({k: T(v) for k, v in sd_np.items()}, strict=True)
+        nets.append(m.to(dev).eval())
+        sds.append(O.to_torch_sd(sd_np))
+    fns = [(lambda e, sd=sd: O.generic_mlp(sd, e, 8, [4], 63, 0, False)) for sd in sds]
     embed_fn, _ = embedder.get_embedder(10, 3, 0)
     embeddirs_fn = None
     q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
                                                                 embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
-    g = cases.g7_inputs(n=301, seed=57)                          # not a multiple of 4: a partly filled last workgroup
     rb8 = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), g["near"], g["far"])[:, :8].contiguous()
     with torch.no_grad():
-        r = render.render_rays(rb8.to(dev), net, q, 64, retraw=True, N_importance=0, white_bkgd=True)
-        ref = O.render_rays_generic(rb8, net_fn, 64, 0, white_bkgd=True, retraw=True)
-        assert r["raw"].shape == (301, 64, 5)
-        close(r["raw"], ref["raw"], atol=1e-3, rtol=1e-4, what="raw, 5 channels")
-        close(r["rgb_map"], ref["rgb_map"], atol=2e-5, what="rgb coarse only")
-        close(r["acc_map"], ref["acc_map"], atol=2e-5, what="acc coarse only")
-        close(r["disp_map"], ref["disp_map"], atol=2e-5, rtol=1e-4, what="disp coarse only")
-        for S, Ni in ((64, 128), (40, 24)):
-            r = render.render_rays(rb8.to(dev), net, q, S, retraw=True, N_importance=Ni, network_fine=None, white_bkgd=True)
-            ref = O.render_rays_generic(rb8, net_fn, S, Ni, white_bkgd=True)
-            assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"] and r["raw"].shape == (301, S + Ni, 5)
-            close(r["rgb0"], ref["rgb0"], atol=2e-5, what="rgb0")
-            close(r["acc0"], ref["acc0"], atol=2e-5, what="acc0")
-            close(r["z_std"], ref["z_std"], atol=2e-3, what="z_std")
-            d = (r["rgb_map"].cpu() - ref["rgb_map"]).abs()
-            db = float(-10 * torch.log10(((r["rgb_map"].cpu() - ref["rgb_map"]) ** 2).mean()))
-            print(f"\n[parity] no-viewdirs fused S={S} Ni={Ni}: within 2e-4 {float((d <= 2e-4).float().mean()):.4f}, max {float(d.max()):.2e}, PSNR {db:.1f} dB")
+        assert render.fused_plan(q, nets) == (10, 0, 0)
+        r = render.render_rays(rb8.to(dev), nets[0], q, 64, retraw=True, N_importance=0, white_bkgd=True)
+        assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "raw"] and r["raw"].shape == (256, 64, 5)
+        close(r["raw"][:16], ref["c_raw"], atol=1e-3, rtol=1e-4, what="raw, 5 channels")
+        close(r["rgb_map"], ref["c_rgb_map"], atol=2e-5, what="rgb coarse only")
+        close(r["acc_map"], ref["c_acc_map"], atol=2e-5, what="acc coarse only")
+        close(r["disp_map"], ref["c_disp_map"], atol=2e-5, rtol=1e-4, what="disp coarse only")
+        r = render.render_rays(rb8.to(dev), nets[0], q, 64, retraw=True, N_importance=128, network_fine=nets[1], white_bkgd=True)
+        assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"] and tuple(r["raw"].shape) == tuple(ref["h_raw_shape"])
+        close(r["rgb0"], ref["h_rgb0"], atol=2e-5, what="rgb0")
+        close(r["acc0"], ref["h_acc0"], atol=2e-5, what="acc0")
+        close(r["disp0"], ref["h_disp0"], atol=2e-5, rtol=1e-4, what="disp0")
+        close(r["z_std"], ref["h_z_std"], atol=2e-3, what="z_std")
+        for k in ("rgb_map", "acc_map"):
+            d = (r[k].cpu() - T(ref[f"h_{k}"])).abs()
+            db = float(-10 * torch.log10(((r[k].cpu() - T(ref[f"h_{k}"])) ** 2).mean()))
+            print(f"\n[parity] no-viewdirs fused 64+128 vs the reference render, {k}: within 2e-4 {float((d <= 2e-4).float().mean()):.4f}, max {float(d.max()):.2e}, PSNR {db:.1f} dB")
             assert float((d <= 2e-4).float().mean()) >= 0.92 and float(d.max()) <= 2e-2 and db >= 70.0
+        # ragged sizes (301 rays: a partly filled last workgroup; 40+24 samples) against the CPU oracle, one net for both passes
+        g2 = cases.g7_inputs(n=301, seed=58)
+        rb2 = O.make_ray_batch(T(g2["rays_o"]), T(g2["rays_d"]), g2["near"], g2["far"])[:, :8].contiguous()
+        r = render.render_rays(rb2.to(dev), nets[0], q, 40, retraw=True, N_importance=24, network_fine=None, white_bkgd=False)
+        o = O.render_rays_generic(rb2, fns[0], 40, 24, white_bkgd=False)
+        assert r["raw"].shape == (301, 64, 5)
+        close(r["rgb0"], o["rgb0"], atol=2e-5, what="ragged rgb0")
+        d = (r["rgb_map"].cpu() - o["rgb_map"]).abs()
+        print(f"\n[parity] no-viewdirs fused 40+24, 301 rays vs oracle: within 2e-4 {float((d <= 2e-4).float().mean()):.4f}, max {float(d.max()):.2e}")
+        assert float((d <= 2e-4).float().mean()) >= 0.92 and float(d.max()) <= 2e-2
         # the generic layer-by-layer path (an opaque closure hides the encoder, so no fused plan) gives the same image
         opaque = lambda a, b, c, _q=q: _q(a, b, c)
-        assert render.fused_plan(opaque, [net, None]) is None
-        a = render.render_rays(rb8.to(dev), net, q, 64, N_importance=0, white_bkgd=True, retraw=True)
-        b = render.render_rays(rb8.to(dev), net, opaque, 64, N_importance=0, white_bkgd=True, retraw=True)
+        assert render.fused_plan(opaque, [nets[0], None]) is None
+        a = render.render_rays(rb8.to(dev), nets[0], q, 64, N_importance=0, white_bkgd=True, retraw=True)
+        b = render.render_rays(rb8.to(dev), nets[0], opaque, 64, N_importance=0, white_bkgd=True, retraw=True)
         close(a["raw"], b["raw"], atol=2e-4, rtol=1e-4, what="fused vs generic raw")
         close(a["rgb_map"], b["rgb_map"], atol=2e-5, what="fused vs generic rgb")
         # 4-channel head, empty batch, and the wrong column count is an error of the C ABI, not a wrong image
-        net4 = __import__("swnerf.model", fromlist=["x"]).vallina_NeRF(**dict(kw, output_ch=4)).to(dev).eval()
-        r4 = render.render_rays(rb8.to(dev)[:9], net4, q, 64, retraw=True, white_bkgd=False)
-        assert r4["raw"].shape == (9, 64, 4) and bool(torch.isfinite(r4["rgb_map"]).all())
-        sd4 = {k: v.detach().cpu() for k, v in net4.state_dict().items()}
-        ref4 = O.render_rays_generic(rb8[:9], lambda e: O.generic_mlp(sd4, e, 8, [4], 63, 0, False), 64, 0, white_bkgd=False, retraw=True)
-        close(r4["raw"], ref4["raw"], atol=1e-3, rtol=1e-4, what="raw, 4 channels")
-        assert render.render_rays(rb8.to(dev)[:0], net, q, 64, N_importance=16)["rgb_map"].shape == (0, 3)
+        net4 = model.vallina_NeRF(**dict(cases.G12_NET, output_ch=4))
+        sd4 = {k: v for k, v in cases.g12_weights()[0].items()}
+        sd4["output_linear.weight"], sd4["output_linear.bias"] = sd4["output_linear.weight"][:4], sd4["output_linear.bias"][:4]
+        net4.load_state_dict({k: T(v) for k, v in sd4.items()})
+        r4 = render.render_rays(rb8.to(dev)[:9], net4.to(dev).eval(), q, 64, retraw=True, white_bkgd=True)
+        assert r4["raw"].shape == (9, 64, 4)
+        close(r4["raw"], ref["c_raw"][:9, :, :4], atol=1e-3, rtol=1e-4, what="raw, 4 channels")
+        close(r4["rgb_map"], ref["c_rgb_map"][:9], atol=2e-5, what="rgb, 4-channel head")
+        assert render.render_rays(rb8.to(dev)[:0], nets[0], q, 64, N_importance=16)["rgb_map"].shape == (0, 3)
         with pytest.raises(RuntimeError):
-            render.render_pass(torch.zeros((4, 11), device=dev), net, 64)
+            render.render_pass(torch.zeros((4, 11), device=dev), nets[0], 64)
 
 
 def test_generic_training_matches_autograd(dev):

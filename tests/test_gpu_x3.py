@@ -203,3 +203,46 @@ def test_x3_argument_checks(sw, dev):
     a.kind = _lib.NET_CANON
     assert _lib.lib().swnerf_render_pass_x3(a, 2, None) == -1 and b"terms" in _lib.lib().swnerf_last_error()
     assert _lib.lib().swnerf_packed_x3_floats_kind(7) == 0
+
+
+# ---- against the REFERENCE: the golden fixtures (round-2 VERDICT: the tests above compare the bf16x3 pass with this library's
+# own fp32 pass only).  Floors = measured on MI355X (printed below) - 3 dB, never under the 45 dB SURVEY.md 8d asks of a
+# reduced-precision path.  The fp32 pass's own PSNR against the same goldens (test_gpu_parity.py) is the yardstick: C2
+# 78.9 dB, D-NeRF t = 0.5 57.7 dB.
+X3_GOLDEN_FLOORS = {("C2", "bf16x3"): 58.0, ("C2", "bf16x3-fine"): 75.0, ("dnerf t=0.5", "bf16x3"): 45.0, ("dnerf t=0.5", "bf16x3-fine"): 52.0}
+
+
+def test_x3_against_the_reference_goldens(sw, dev, nets, golden):
+    import swnerf.render_dnerf  # noqa
+    embed_fn, _ = sw.embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = sw.embedder.get_embedder(4, 3, 0)
+    embedtime_fn, _ = sw.embedder.get_embedder(10, 1, 0)
+    q = lambda inputs, viewdirs, network_fn: sw.render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+    qd = lambda inputs, viewdirs, ts, network_fn: sw.render_dnerf.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn,
+                                                                             embeddirs_fn=embeddirs_fn, embedtime_fn=embedtime_fn, embd_time_discr=True)
+    dn = sw.model.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27,
+                                   input_ch_time=21, use_viewdirs=True, embed_fn=embed_fn, zero_canonical=True)
+    dn.load_state_dict({k: T(v) for k, v in cases.weights_dnerf().items()})
+    dn = dn.to(dev).eval()
+    from oracle import nerf_oracle as O
+    g7, g8 = cases.g7_inputs(), cases.g8_inputs()
+    rb7 = O.make_ray_batch(T(g7["rays_o"]), T(g7["rays_d"]), g7["near"], g7["far"]).to(dev)
+    rb8 = O.make_ray_batch(T(g8["rays_o"]), T(g8["rays_d"]), g8["near"], g8["far"], frame_time=0.5).to(dev)
+    ref7, ref8 = golden("g7_c2"), golden("g8_dnerf_t5")
+    measured = {}
+    for mode in ("fp32", "bf16x3", "bf16x3-fine"):
+        prev = sw.render.set_precision(mode)
+        try:
+            with torch.no_grad():
+                a = sw.render.render_rays(rb7, nets[0], q, 64, N_importance=128, network_fine=nets[1], white_bkgd=True)
+                b = sw.render_dnerf.render_rays(rb8, dn, qd, 64, N_importance=128, white_bkgd=True)
+        finally:
+            sw.render.set_precision(prev)
+        measured[("C2", mode)] = psnr(a["rgb_map"].cpu(), T(ref7["rgb_map"]))
+        measured[("dnerf t=0.5", mode)] = psnr(b["rgb_map"].cpu(), T(ref8["rgb_map"]))
+        if mode == "bf16x3-fine":                      # the coarse pass stayed fp32: its outputs are the parity path's, to the reference's 2e-5
+            assert float((a["rgb0"].cpu() - T(ref7["rgb0"])).abs().max()) <= 2e-5
+    for k, v in measured.items():
+        print(f"\n[x3 vs golden] {k[0]}, {k[1]}: PSNR of rgb_map against the REFERENCE's render {v:.1f} dB")
+    for k, floor in X3_GOLDEN_FLOORS.items():
+        assert measured[k] >= max(floor, 45.0), (k, measured[k], floor)

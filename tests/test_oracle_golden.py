@@ -207,3 +207,32 @@ def test_g11_generic_shapes(golden):
     ret = O.render_rays_generic(rb, lambda e: O.generic_mlp(sdn, e, kwn["D"], kwn["skips"], kwn["input_ch"], 0, False), 32, 32, white_bkgd=True)
     for k in ("rgb0", "acc0", "rgb_map", "acc_map", "z_std"):
         np.testing.assert_allclose(ret[k].numpy(), ref[f"rr_{k}"], atol=2e-5 if k.endswith("0") else 5e-4, err_msg=k)
+
+
+def test_g12_render_rays_without_viewdirs(golden):
+    """The oracle's render_rays without view directions (two nets, output_ch 5) against the reference's own
+    nerf/run.py render_rays on NON-degenerate weights (tests/golden/make_golden_noview.py): the coarse-only outputs and
+    raw to 1e-5-level, the image behind the hierarchical resampling to the conditioning of sample_pdf (the oracle runs the
+    same ATen CPU kernels as the reference, so it is bit-close here too)."""
+    ref = golden("g12_noview")
+    g = cases.g12_inputs()
+    ws = cases.g12_weights()
+    assert int(ref["checksum"][0]) == int(cases.checksum(g["rays_o"], g["rays_d"], *[v for sd in ws for v in sd.values()])[0])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    o_, d_ = T(g["rays_o"]), T(g["rays_d"])
+    rb = torch.cat([o_, d_, g["near"] * torch.ones_like(d_[:, :1]), g["far"] * torch.ones_like(d_[:, :1])], -1)
+    fns = [(lambda e, sd=O.to_torch_sd(sd_np): O.generic_mlp(sd, e, 8, [4], 63, 0, False)) for sd_np in ws]
+    with torch.no_grad():
+        c = O.render_rays_generic(rb, fns[0], 64, 0, white_bkgd=True, retraw=True)
+        h = O.render_rays_two_nets_generic(rb, fns[0], fns[1], 64, 128, white_bkgd=True)
+    assert 0.2 < float(ref["c_acc_map"].mean()) < 0.8 and float(ref["c_rgb_map"].std()) > 0.05      # the case is not vacuous
+    for k in ("rgb_map", "disp_map", "acc_map"):
+        np.testing.assert_allclose(c[k].numpy(), ref[f"c_{k}"], atol=2e-5, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(c["raw"][:16].numpy(), ref["c_raw"], atol=2e-4, rtol=1e-4)
+    assert tuple(ref["h_raw_shape"]) == (256, 192, 5)
+    for k in ("rgb0", "disp0", "acc0"):
+        np.testing.assert_allclose(h[k].numpy(), ref[f"h_{k}"], atol=2e-5, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(h["z_std"].numpy(), ref["h_z_std"], atol=1e-4)
+    for k in ("rgb_map", "acc_map"):
+        d = np.abs(h[k].numpy() - ref[f"h_{k}"])
+        assert float((d <= 2e-4).mean()) >= 0.97 and float(d.max()) <= 2e-2, (k, float((d <= 2e-4).mean()), float(d.max()))
