@@ -456,12 +456,13 @@ def test_render_rays_static_golden(sw, dev, golden, nets):
     assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"]
     assert r["raw"].shape == (1024, 192, 4)
     # the static render_rays does not return its depths (nerf/run.py:405-416): ours from the coarse pass alone, the
-    # reference's from the oracle (pinned to the same goldens) - for the 32 rays whose raw the golden holds
+    # reference's from golden G7z - captured inside the very call that produced g7_c2 (tests/golden/make_golden_depths.py) -
+    # for the 32 rays whose raw the golden holds.  (The oracle's depths will not do: run on 32 rays instead of 1024 its
+    # sgemm blocks differently and its samples differ from the reference's in the last bit - measured 5e-2 in raw.)
     z_ours = sw.render.render_pass(rb[:32], nets["coarse"], 64, white_bkgd=True, want=[], n_importance=128)["z_fine"]
-    sd_c, sd_f = (O.to_torch_sd(s_) for s_ in cases.weights_static())
-    z_ref = O.render_rays(rb[:32].cpu(), sd_c, sd_f, 64, 128, white_bkgd=True)["z_vals"]
+    z_ref = golden("g7_c2_depths")["z_vals"]
     _cmp(r, golden("g7_c2"), ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "raw"], "C2", psnr_min=75.0,   # measured 78.9
-         z_pair=(z_ours, z_ref))
+         z_pair=(z_ours, z_ref), min_matched=0.6)
     gs = cases.g7_inputs(n=256, seed=11)
     r = sw.render.render_rays(_rb(gs, dev), nets["coarse"], q, 64, N_importance=128, network_fine=None, white_bkgd=False, lindisp=True)
     _cmp(r, golden("g7_lindisp"), ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], "lindisp")
@@ -506,7 +507,8 @@ def test_c3_ndc_batch_full_size_properties(sw, dev, nets):
     rb = O.make_ray_batch(T(o[sel]), T(d[sel]), 0., 1., ndc=True, H=378, W=504, focal=float(Kf[0][0]))
     ref = O.render_rays(rb, sd_c, sd_f, 64, 128, white_bkgd=False)
     got = dict(rgb_map=full[0][sel], disp_map=full[1][sel], acc_map=full[2][sel], **{k: v[sel] for k, v in full[3].items()})
-    _cmp(got, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], "C3 full size", psnr_min=86.0)
+    # (hard bound: NDC disparities run up to ~60; measured max relative |d disp| 2.6e-2 on this subset, 1.7e-2 on the lindisp golden)
+    _cmp(got, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], "C3 full size", psnr_min=86.0, hard=4e-2)
 
 
 def test_render_full_image_c2w_and_chunking(sw, dev, nets):
@@ -644,7 +646,7 @@ def test_render_rays_dnerf_golden(sw, dev, golden, nets):
         assert list(r.keys()) == ["rgb_map", "disp_map", "acc_map", "z_vals", "position_delta", "raw", "z_std"]
         if tv == 0.0:
             _cmp(r, ref, ["rgb_map", "disp_map", "acc_map", "z_vals", "z_std", "position_delta", "raw"], f"dnerf t={tv}", psnr_min=78.0,   # measured 81.2
-                 z_pair=(r["z_vals"][:32], ref["z_vals"][:32]))
+                 z_pair=(r["z_vals"][:32], ref["z_vals"][:32]), min_matched=0.6)      # measured 70.8 % bit-equal depths; there raw 6e-6, dx 0
             continue
         # t != 0: the deformation output dx (ours differs from the reference by <= 2.1e-7, checked in
         # the no-resampling block below) enters gamma(x+dx), whose top band multiplies it by 2^9, BEFORE
@@ -671,11 +673,11 @@ def test_render_rays_dnerf_golden(sw, dev, golden, nets):
               f"(row bound {row_bound.max():.3f})")
         assert np.all(np.abs(gz - rz) <= row_bound), "dnerf t=0.5 z_vals: an element moved by more than one coarse interval"
         close_mostly(r["z_vals"], ref["z_vals"], atol=2e-5, frac=0.9, hard=float(row_bound.max()), what="dnerf t=0.5 z_vals")
-        # per-sample outputs at equal depths: dx does not depend on the resampling noise at all (2e-6), raw carries the
-        # gamma(x+dx) amplification of dx's last bits (2^9 band): 1e-2 + 1e-3 |ref|
+        # per-sample outputs at equal depths - at least the 64 coarse depths of every ray (measured 41.9 %): the limits of the
+        # pass without resampling (measured there: dx 1.7e-7, raw 9.3e-5)
         cmp_per_sample_at_matched_depths(r["position_delta"], ref["position_delta"], r["z_vals"], ref["z_vals"], "dnerf t=0.5 position_delta",
-                                         atol=2e-6, rtol=0.0, min_matched=0.33)     # at least the 64 coarse depths of every ray
-        cmp_per_sample_at_matched_depths(r["raw"], ref["raw"], r["z_vals"], ref["z_vals"], "dnerf t=0.5 raw", atol=1e-2, rtol=1e-3, min_matched=0.33)
+                                         atol=2e-6, rtol=0.0, min_matched=0.35)
+        cmp_per_sample_at_matched_depths(r["raw"], ref["raw"], r["z_vals"], ref["z_vals"], "dnerf t=0.5 raw", atol=1e-3, rtol=1e-4, min_matched=0.35)
         # the same pass with NO resampling in between is tight
         r0 = sw.render_dnerf.render_rays(_rb(g, dev, tv), nets["dn"], qd, 64, retraw=True, N_importance=0, white_bkgd=True)
         o0 = O.render_rays_dnerf(_rb(g, "cpu", tv)[:128], O.to_torch_sd(cases.weights_dnerf()), 64, 0, white_bkgd=True, retraw=True)
