@@ -534,11 +534,15 @@ def worker(args):
     fine_ms = float(np.mean(ms_kernel)) if ms_kernel else float("nan")
     fine_flop = n_local * S_FINE * sc["flop_per_fine_row"]
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath) and cfg == "C2":
+        # HBM/fabric bytes per fine-pass launch from the PMC passes of the round named in the file (tools/profile_r03.sh ->
+        # tools/make_roofline_traffic.py); a counter figure cannot be collected inside this run
         try:
-            traffic = json.load(open(tpath)).get("fine_pass_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("fine_pass_hbm_bytes_per_launch")
+            traffic_src = f"round {tj.get('round')}: {tj.get('source')}"
         except Exception:
             traffic = None
 
@@ -562,7 +566,7 @@ def worker(args):
                    "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE, "clock_prewarm_s": PREWARM_S,
                    "parallelism": f"ray-sharded dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)",
                      "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
                      "step_frac": rays_per_step / world * sc["flop_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},

@@ -123,7 +123,7 @@ __device__ __forceinline__ void pass_startup(const PassDev& P, const float* w0, 
 // SWNERF_WARM / SWNERF_SKEW (experiments: tools/probe_small_batch.py) override the defaults.
 static inline void pass_startup_args(PassDev& P, unsigned grid_x, int steps) {
     static const int env_warm = [] { const char* e = getenv("SWNERF_WARM"); return e ? atoi(e) : 1; }();
-    static const int env_skew = [] { const char* e = getenv("SWNERF_SKEW"); return e ? atoi(e) : 1; }();
+    static const int env_skew = [] { const char* e = getenv("SWNERF_SKEW"); return e ? atoi(e) : 2; }();
     const unsigned first_round = grid_x < 256u ? grid_x : 256u;      // one workgroup per CU is resident
     P.warm_blocks = (int)(first_round / 8u);
     P.warm_steps = (env_warm && P.warm_blocks > 0) ? steps + SW_TAIL : 0;

@@ -538,6 +538,7 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
         lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
     }
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
+    pass_startup_args(P, grid.x, SW_CANON_STEPS);
     hipLaunchKernelGGL((render_pass_kernel<false, true>), grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_train launch");
 }
@@ -586,6 +587,7 @@ extern "C" int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args, floa
     P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     const size_t lds = PassLds<true, true>::FIXED * sizeof(float);
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
+    pass_startup_args(P, grid.x, SW_DEFORM_STEPS + SW_CANON_STEPS);
     hipLaunchKernelGGL((render_pass_kernel<true, true>), grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_train_dnerf launch");
 }
