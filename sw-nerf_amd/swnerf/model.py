@@ -14,6 +14,7 @@ register-resident dX chain + TN MFMA GEMMs (`_MlpTrain`, `_DnerfTrain`); gradien
 not produced (rays are data in the reference's train()).
 """
 import ctypes
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401
@@ -62,10 +63,57 @@ def _zero_grads(params):
     return [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
 
 
+GEMM_STREAMS = int(os.environ.get("SWNERF_GEMM_STREAMS", "2"))    # side streams the weight-gradient GEMMs of a chunk fan out over (0/1: off)
+_SIDE_STREAMS = {}
+
+
+class _Fan:
+    """The weight-gradient GEMMs of one row chunk are independent of each other (each reads grad / act and accumulates into
+    its own C with atomics), but every launch ends with an epilogue of 64 K float atomics per workgroup (~50 us chip-wide)
+    during which the matrix pipe idles, and starts with a ramp.  Issued round-robin on a few side streams, a GEMM's
+    workgroups start on the CUs the previous GEMM's workgroups have left (each needs a whole CU: >128 KB of LDS), so one
+    launch's epilogue runs under the next one's main loop.  fork(): the side streams wait for the current stream (the
+    backward kernel that produced `grad`); next(): the stream handle for the next launch; join(): the current stream waits
+    for all of them (before `grad` is overwritten / the gradients are read)."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        n = GEMM_STREAMS if GEMM_STREAMS > 1 else 0
+        key = (device.index, n)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        self.side = _SIDE_STREAMS[key]
+        self.i = 0
+
+    def fork(self):
+        if self.side:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            for s in self.side:
+                s.wait_event(ev)
+
+    def next(self):
+        if not self.side:
+            return ctypes.c_void_p(self.main.cuda_stream)
+        s = self.side[self.i % len(self.side)]
+        self.i += 1
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def join(self):
+        for s in self.side:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.main.wait_event(ev)
+
+
+def _st(st):
+    return st.next() if isinstance(st, _Fan) else st
+
+
 def _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias):
     """C[:, c_col:c_col+Ni] += A[:, a_col:a_col+No]^T . B[:, b_col:b_col+Ni];  bias += column sums of that A block"""
     _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
-                                C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(bias), st), "gemm_tn")
+                                C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(bias), _st(st)), "gemm_tn")
 
 
 def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col=0, Ni2=0, C2=None, c2_col=0,
@@ -75,7 +123,7 @@ def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col
     ld = lambda T_: 0 if T_ is None else T_.stride(0)
     _lib.check(L.swnerf_gemm_tn_fused(off(A, a_col), ld(A), off(B, b_col), ld(B), M, off(C, c_col), ld(C), _lib.ptr(bias),
                                       off(B2, b2_col), ld(B2), Ni2, off(C2, c2_col), ld(C2),
-                                      off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3), st), "gemm_tn_fused")
+                                      off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3), _st(st)), "gemm_tn_fused")
 
 
 def _rgb4_buffers(device):

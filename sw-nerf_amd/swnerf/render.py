@@ -252,7 +252,7 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
-        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish
+        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -273,6 +273,7 @@ class _FusedPassTrain(torch.autograd.Function):
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
         grad = torch.empty((min(N, chunk) * rows_per_ray, act.shape[1]), dtype=torch.float32, device=rb.device)
         d_raw = torch.empty((min(N, chunk) * rows_per_ray, 4), dtype=torch.float32, device=rb.device)
+        fan = _Fan(rb.device)                                    # the GEMMs of a chunk fan out over side streams (model._Fan)
         for r0 in range(0, N, chunk):
             r1 = min(N, r0 + chunk)
             n, m = r1 - r0, (r1 - r0) * rows_per_ray
@@ -283,7 +284,9 @@ class _FusedPassTrain(torch.autograd.Function):
                 _lib.ptr(grad), _lib.ptr(d_raw), st),
                 "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
+            fan.fork()
+            _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
+            fan.join()                                           # before the next chunk's backward kernel overwrites grad / d_raw
         _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
         _rgb4_finish(g, rgb4)
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))

@@ -118,7 +118,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
-                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot)
+                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan)
         from . import render as _r
         rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
@@ -131,9 +131,10 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         g = _zero_grads(params)                                   # 24 `_occ` tensors then 18 `_time` / `_time_out`
         slot_bufs, rgb4, dbufs = _slot_buffers(rb.device), _rgb4_buffers(rb.device), _deform_slot_buffers(rb.device)
         rows_per_ray = act.shape[0] // N
-        # two gradient buffers per chunk; 786 432 rows (= a 4096-ray fine pass in ONE chunk: 15 GB) - every extra chunk costs
-        # one atomic epilogue for each of the 20 GEMMs, and the op path this replaces held the whole pass anyway
-        chunk = max(4, (2 * _r.TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
+        # two gradient buffers (canonical + deformation net) per chunk of TRAIN_BWD_CHUNK_ROWS rows (2 x 3.8 GB); the GEMMs of a
+        # chunk fan out over side streams (model._Fan), which hides most of what an extra chunk used to cost (one atomic
+        # epilogue per GEMM).  Round 2 held the whole fine pass in one chunk: 15 GB of gradients, 29.6 GiB peak.
+        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
         packed_bwd = net.packed_bwd(_lib.BWD_DNERF_FUSED)
         mask_per_ray = bits.numel() // N
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
@@ -142,6 +143,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         grad, grad_d, d_raw, g_dx = new(nrow, act.shape[1]), new(nrow, act.shape[1]), new(nrow, 4), new(nrow, 4)
         gc, gd = g[:24], g[24:]
         Cpos, Cdir = net.input_ch, net.input_ch_views
+        fan = _Fan(rb.device)
         for r0 in range(0, N, chunk):
             r1 = min(N, r0 + chunk)
             n, m = r1 - r0, (r1 - r0) * rows_per_ray
@@ -153,8 +155,10 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
                 _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)), _lib.ptr(grad), _lib.ptr(grad_d), _lib.ptr(d_raw), _lib.ptr(g_dx), st),
                 "render_pass_backward_dnerf")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            _canon_weight_grads_slots(L, st, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4)
-            _deform_weight_grads_slots(L, st, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs)
+            fan.fork()
+            _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4)
+            _deform_weight_grads_slots(L, fan, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs)
+            fan.join()
         _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc)
         _rgb4_finish(gc, rgb4)
         _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)
