@@ -361,7 +361,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             trunk_pass<false, false, false, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
             // outputs = output_linear(h) (model.py:59-60): [rgb(3), sigma, (5th, unused by raw2outputs)]
             float o5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            head_valu_rt<8>(in, ws, (a.out_ch == 5 && !a.raw) ? 4 : a.out_ch, o5);   // the fifth channel only shows in `raw`
+            const int nout = (a.out_ch == 5 && !a.raw) ? 4 : a.out_ch;              // the fifth channel only shows in `raw`
+            head_valu_rt<8>(in, ws, nout, o5);
+            ws.bias += (a.out_ch - nout) * 8 * SW_BIAS_TILE_FLOATS;                 // skip the weight tiles of a channel not evaluated
             rgb[0] = o5[0] + ws.bias[0]; rgb[1] = o5[1] + ws.bias[1]; rgb[2] = o5[2] + ws.bias[2];
             head[0] = o5[3] + ws.bias[3]; head[1] = 0.f; head[2] = 0.f;
             extra = o5[4] + ws.bias[4];
