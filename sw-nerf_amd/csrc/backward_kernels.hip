@@ -10,6 +10,7 @@
 #include "lds_dma.h"
 #include "host_util.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -430,6 +431,130 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same plan for the SKINNY weight-gradient GEMMs of a training step - pts_linears.0 (256 x 64 slots of gamma(x)),
+// views_linears.0 (128 x 256 and 128 x 32), rgb_linear (4 x 128), the deformation net's gamma(t) columns and _time_out:
+// 6 % of the FLOPs that took 16 % of the GEMM time on the single-buffered narrow kernel above (2 TB/s).  One 16-wave
+// workgroup per CU-sized row slice, 32-row slabs of A and B double buffered in LDS by LDS-DMA (1 KiB row pitch whatever
+// the operand's width: lanes past its last column re-read its first 16 bytes, never another row), one barrier per slab.
+// The WO x WI wave grid covers C with TO x TI accumulator tiles per wave; waves beyond the grid only help with the DMA.
+// These shapes are HBM bound: what matters is that a whole slab per CU is always in flight.
+template <int TO, int TI, int WO, int WI>
+__global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
+    static_assert(WO * WI <= 16 && 32 * TO * WO <= 256 && 32 * TI * WI <= 256, "wave grid must fit the 16-wave workgroup and the 256-column slabs");
+    extern __shared__ __attribute__((aligned(16))) float gd_lds[];           // [2][GD_BUF_FLOATS]
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool active = w < WO * WI;
+    const int o0 = 32 * TO * (w % WO), i0 = 32 * TI * (w / WO);
+    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
+    const int nslab = (mlen + GD_SLAB - 1) / GD_SLAB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)gd_lds);
+    const unsigned voff_a = (4 * lane < P.No) ? (unsigned)lane * 16u : 0u;
+    const unsigned voff_b = (4 * lane < P.Ni) ? (unsigned)lane * 16u : 0u;
+    const char* cur[4];
+    int64_t step[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int id = w * 4 + q, row = id & 31;
+        cur[q] = reinterpret_cast<const char*>(id < 32 ? P.A + (m0 + row) * P.lda : P.B + (m0 + row) * P.ldb);
+        step[q] = (int64_t)GD_SLAB * 4 * (id < 32 ? P.lda : P.ldb);
+    }
+    auto issue = [&](int sl) {
+        const bool full = (sl + 1) * GD_SLAB <= mlen;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = w * 4 + q, row = id & 31;
+            const char* g = cur[q];
+            if (!full) {
+                const int64_t r = m0 + min(sl * GD_SLAB + row, mlen - 1);
+                g = reinterpret_cast<const char*>(id < 32 ? P.A + r * P.lda : P.B + r * P.ldb);
+            }
+            ws_dma(g, id < 32 ? voff_a : voff_b, lds0 + (unsigned)((sl & 1) * GD_BUF_FLOATS * 4 + id * 1024));
+            cur[q] += step[q];
+        }
+    };
+    f32x16 acc[TO * TI];
+    float bs[TO];
+#pragma unroll
+    for (int k = 0; k < TO * TI; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < TO; ++a) bs[a] = 0.f;
+    issue(0);
+#pragma nounroll
+    for (int sl = 0; sl < nslab; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+        if (sl + 1 < nslab) issue(sl + 1);
+        if (!active) continue;
+        const float* Ab = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+        const float* As = Ab + o0 + i;
+        const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
+        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
+        float a[TO], b[TI];
+#pragma unroll
+        for (int x = 0; x < TO; ++x) a[x] = As[hp * 256 + 32 * x];
+#pragma unroll
+        for (int x = 0; x < TI; ++x) b[x] = Bs[hp * 256 + 32 * x];
+#pragma unroll
+        for (int s = 0; s < GD_SLAB / 2; ++s) {
+            const int row = 2 * s + hp;
+            const bool ok = row < valid;
+            float c[TO], d[TI];
+#pragma unroll
+            for (int x = 0; x < TO; ++x) c[x] = ok ? a[x] : 0.f;
+#pragma unroll
+            for (int x = 0; x < TI; ++x) d[x] = b[x];
+            const int nr = (min(row + 2, GD_SLAB - 1)) * 256;   // (the last iteration re-reads the slab's last rows: unused)
+#pragma unroll
+            for (int x = 0; x < TO; ++x) a[x] = As[nr + 32 * x];
+#pragma unroll
+            for (int x = 0; x < TI; ++x) b[x] = Bs[nr + 32 * x];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < TO; ++x) bs[x] += c[x];
+#pragma unroll
+            for (int x = 0; x < TO; ++x)
+#pragma unroll
+                for (int y = 0; y < TI; ++y) acc[x * TI + y] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[x], d[y], acc[x * TI + y], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!active) return;
+    // C/D map: register r of lane (j = i, h = hp) of tile (x, y) is row o0 + 32 x + frow(r,h), column i0 + 32 y + j
+#pragma unroll
+    for (int x = 0; x < TO; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y) {
+            const int col = i0 + 32 * y + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * x + sw_frow(r, hp);
+                if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[x * TI + y][r]);
+            }
+        }
+    if (P.bias && i0 == 0) {
+#pragma unroll
+        for (int x = 0; x < TO; ++x) {
+            const float v = bs[x] + __shfl_xor(bs[x], 32, 64);
+            if (hp == 0 && o0 + 32 * x + i < P.No) atomicAdd(P.bias + o0 + 32 * x + i, v);
+        }
+    }
+}
+
+template <int TO, int TI, int WO, int WI>
+static int gemm_tiled_launch(GemmTN P, void* stream) {
+    int64_t nwg = 256;                                   // one workgroup per CU-sized row slice, whole slabs
+    int64_t rows = ((P.M + nwg - 1) / nwg + GD_SLAB - 1) / GD_SLAB * GD_SLAB;
+    nwg = (P.M + rows - 1) / rows;
+    P.rows_per_wg = rows;
+    hipLaunchKernelGGL((gemm_tn_tiled_kernel<TO, TI, WO, WI>), dim3((unsigned)nwg), dim3(1024), 2 * GD_BUF_FLOATS * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "gemm_tn (tiled) launch");
+}
+
 static int gemm_dma_launch(const GemmFused& F0, void* stream) {
     GemmFused F = F0;
     const int64_t M = F.g.M;
@@ -494,6 +619,15 @@ extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, i
         F.B2 = nullptr; F.ldb2 = 0; F.Ni2 = 0; F.C2 = nullptr; F.ldc2 = 0;
         F.A2 = nullptr; F.lda2 = 0; F.No2 = 0; F.C3 = nullptr; F.ldc3 = 0; F.bias3 = nullptr;
         return gemm_dma_launch(F, stream);
+    }
+    // skinny shapes with 16-byte aligned operands: the double-buffered LDS-DMA kernel with the wave grid that covers C
+    if (aligned && No % 4 == 0 && Ni % 4 == 0 && M >= 4096 && getenv("SWNERF_GEMM_NARROW_OLD") == nullptr) {
+        if (No <= 32 && Ni <= 128) return gemm_tiled_launch<1, 1, 1, 4>(P, stream);     // rgb_linear 4 x 128
+        if (No <= 32 && Ni <= 256) return gemm_tiled_launch<1, 2, 1, 4>(P, stream);     // _time_out 4 x 256
+        if (No <= 128 && Ni <= 32) return gemm_tiled_launch<1, 1, 4, 1>(P, stream);     // views_linears.0, gamma(d) slots 128 x 32
+        if (Ni <= 32) return gemm_tiled_launch<1, 1, 8, 1>(P, stream);                  // _time.0, gamma(t) slots 256 x 32
+        if (Ni <= 64) return gemm_tiled_launch<1, 1, 8, 2>(P, stream);                  // pts_linears.0 / _time.0, gamma(x) slots 256 x 64
+        if (No <= 128 && Ni <= 256) return gemm_tiled_launch<1, 2, 4, 4>(P, stream);    // views_linears.0, feature columns 128 x 256
     }
     // split the rows over ~2 workgroups per CU, at least 256 rows each (whole slabs)
     int64_t nwg = (M + 255) / 256;

@@ -484,6 +484,38 @@ def test_gemm_tn_256x256_dma_path(dev, M):
     assert float((bias - bref.float()).abs().max()) <= 2e-5 * float(bref.abs().max())
 
 
+@pytest.mark.parametrize("No,Ni,a_col,b_col,lda,ldb", [
+    (256, 64, 0, 0, 2432, 96),        # pts_linears.0 / _time.0: d pre_0 x the gamma(x) slots of xs
+    (128, 256, 2304, 2048, 2432, 2432),   # views_linears.0: d pre_views x feature
+    (128, 32, 2304, 64, 2432, 96),    # views_linears.0: x the gamma(d) slots
+    (256, 32, 0, 64, 2432, 96),       # _time.0: x the gamma(t) slots
+    (4, 128, 0, 2304, 4, 2432),       # rgb_linear in its 4-row form: d raw x the view hidden layer
+    (4, 256, 0, 1792, 4, 2432),       # _time_out in its 4-row form
+    (8, 100, 4, 8, 16, 128),          # not a shape of the step: widths that are no multiples of 32
+])
+@pytest.mark.parametrize("M", [4096, 50000 + 7])
+def test_gemm_tn_skinny_shapes(dev, M, No, Ni, a_col, b_col, lda, ldb):
+    """The skinny weight-gradient GEMMs (double-buffered LDS-DMA kernel with a wave grid per shape, round 3) against torch in
+    float64: operands that are column windows of wider buffers, ragged row counts, accumulation into a non-zero window of
+    a wider C, bias column sums, and the columns next to the window untouched."""
+    from swnerf import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(M + 7 * No + Ni)
+    A = torch.randn((M, lda), generator=g).to(dev)
+    B = torch.randn((M, ldb), generator=g).to(dev)
+    C0 = torch.randn((No, Ni + 9), generator=g).to(dev)
+    C, bias = C0.clone(), torch.zeros(No, device=dev)
+    # C's window must keep 4-byte alignment only (atomics); A and B windows are 16-byte aligned here
+    _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, lda, No, B.data_ptr() + 4 * b_col, ldb, Ni, M,
+                                C.data_ptr() + 4 * 5, C.stride(0), _lib.ptr(bias), _lib.stream_of(A)), "gemm_tn")
+    ref = A[:, a_col:a_col + No].double().T @ B[:, b_col:b_col + Ni].double()
+    scale = float(ref.abs().max())
+    assert float((C[:, 5:5 + Ni] - C0[:, 5:5 + Ni] - ref.float()).abs().max()) <= 2e-5 * scale
+    assert torch.equal(C[:, :5], C0[:, :5]) and torch.equal(C[:, 5 + Ni:], C0[:, 5 + Ni:])
+    bref = A[:, a_col:a_col + No].double().sum(0)
+    assert float((bias - bref.float()).abs().max()) <= 2e-5 * float(bref.abs().max())
+
+
 def test_training_loop_through_create_nerf(dev, tmp_path):
     """The core of train() (nerf/run.py:635-735) on the build: create_nerf -> render(**render_kwargs_train) -> img2mse on
     rgb and rgb0 -> backward -> Adam step -> exponential lr decay -> checkpoint.  The loss on a fixed batch must fall."""
