@@ -474,12 +474,25 @@ def worker(args):
     hook.on = False
     render.PASS_HOOK = hook
 
+    pending = []                                         # all-gathers in flight: (work, out)
+
     def gather(px):
+        """The step's collective, issued asynchronously: the all-gather of this step's pixels is enqueued behind the render
+        that produced them and runs on RCCL's stream under the NEXT step's first launch (one collective in flight at most;
+        finish() drains before the clock stops, so every step's gather is inside the timed region)."""
         if not collective:
             return px
         if rehearsal:
             return parallel.gather_pixels(px.cpu(), force=True).to(dev)
-        return parallel.gather_pixels(px, force=True)    # all_gather_into_tensor on device tensors, also at world 1
+        while len(pending) >= 1:
+            pending.pop(0)[0].wait()
+        out, work = parallel.gather_pixels(px, force=True, async_op=True)    # all_gather_into_tensor on device tensors, also at world 1
+        pending.append((work, out))
+        return out
+
+    def finish():
+        while pending:
+            pending.pop(0)[0].wait()
 
     if cfg == "C2":
         o_np, d_np = synth.pick_rays(H, W, K, c2w, N_RAND, seed=2 + rank)
@@ -500,6 +513,7 @@ def worker(args):
             return gather(render_range(lo, hi - lo))
 
     def fence():
+        finish()
         torch.cuda.synchronize(dev)
         if collective:
             dist.barrier()

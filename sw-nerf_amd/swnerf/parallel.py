@@ -9,25 +9,31 @@ import torch.distributed as dist
 from .synth import shard_range
 
 
-def gather_pixels(local, counts=None, group=None, force=False):
+def gather_pixels(local, counts=None, group=None, force=False, async_op=False):
     """all-gather of per-rank [n_local, C] pixel blocks into [sum n, C] on every rank.
     Equal shards use a single all_gather_into_tensor (one RCCL call); ragged shards pad to the
     largest and trim.  A group of one rank returns `local` without a collective unless `force` (bench.py --collective
-    always: the RCCL call of the N > 1 runs, exercised on a one-GPU box)."""
+    always: the RCCL call of the N > 1 runs, exercised on a one-GPU box).
+    async_op (equal shards only): returns (out, work) with the collective enqueued behind the producer of `local` on the
+    backend's own stream - the caller renders on and calls work.wait() before it reads `out` (work is None when no
+    collective was needed): the 1.6 MB gather of a frame then runs under the next frame's first launch instead of in
+    front of it."""
     if not (dist.is_available() and dist.is_initialized()):
         if force:
             raise RuntimeError("swnerf.parallel.gather_pixels(force=True) needs an initialised process group")
-        return local
+        return (local, None) if async_op else local
     if dist.get_world_size(group) == 1 and not force:
-        return local
+        return (local, None) if async_op else local
     world = dist.get_world_size(group)
     n, c = local.shape
     if counts is None:
         counts = [n] * world
     if all(k == counts[0] for k in counts):
         out = torch.empty((world * n, c), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    if async_op:
+        raise ValueError("swnerf.parallel.gather_pixels: async_op needs equal shards")
     m = max(counts)
     pad = torch.zeros((m, c), dtype=local.dtype, device=local.device)
     pad[:n] = local

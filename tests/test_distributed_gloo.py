@@ -37,6 +37,9 @@ def _worker(rank, world, port, q):
     # equal shards -> the single-collective path; ragged shards -> pad/trim path
     a = torch.full((5, 3), float(rank))
     same = parallel.gather_pixels(a)
+    same_async, work = parallel.gather_pixels(a, async_op=True)
+    work.wait()
+    assert torch.equal(same, same_async)
     rag = parallel.gather_pixels(torch.full((3 + rank, 2), float(rank)), counts=[3 + r for r in range(world)])
     # data-parallel training: one flat all-reduce of the gradients (each rank saw half of the rays)
     lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
@@ -113,13 +116,16 @@ def test_gather_pixels_force_runs_the_collective_at_world_1():
     try:
         calls = []
         real = dist.all_gather_into_tensor
-        dist.all_gather_into_tensor = lambda out, inp, group=None: (calls.append(1), real(out, inp, group=group))[1]
+        dist.all_gather_into_tensor = lambda out, inp, group=None, async_op=False: (calls.append(1), real(out, inp, group=group, async_op=async_op))[1]
         try:
             assert parallel.gather_pixels(a) is a and not calls                 # default: no collective for one rank
             g = parallel.gather_pixels(a, force=True)
         finally:
             dist.all_gather_into_tensor = real
         assert calls == [1] and g is not a and torch.equal(g, a)
+        g2, work = parallel.gather_pixels(a, force=True, async_op=True)          # bench.py's form: wait before reading
+        work.wait()
+        assert torch.equal(g2, a) and parallel.gather_pixels(a, async_op=True) == (a, None)
     finally:
         dist.destroy_process_group()
 
