@@ -131,10 +131,11 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         g = _zero_grads(params)                                   # 24 `_occ` tensors then 18 `_time` / `_time_out`
         slot_bufs, rgb4, dbufs = _slot_buffers(rb.device), _rgb4_buffers(rb.device), _deform_slot_buffers(rb.device)
         rows_per_ray = act.shape[0] // N
-        # two gradient buffers (canonical + deformation net) per chunk of TRAIN_BWD_CHUNK_ROWS rows (2 x 3.8 GB); the GEMMs of a
-        # chunk fan out over side streams (model._Fan), which hides most of what an extra chunk used to cost (one atomic
-        # epilogue per GEMM).  Round 2 held the whole fine pass in one chunk: 15 GB of gradients, 29.6 GiB peak.
-        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
+        # two gradient buffers (canonical + deformation net) per chunk: half of TRAIN_BWD_CHUNK_ROWS rows each, so that a chunk
+        # holds the 3.8 GB the static backward's chunk does; the GEMMs of a chunk fan out over side streams (model._Fan), which
+        # hides most of what an extra chunk used to cost (one atomic epilogue per GEMM).  Round 2 held the whole fine pass in
+        # one chunk: 15 GB of gradients, 29.6 GiB peak for a 4096-ray step.
+        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // 2 // rows_per_ray) // 4 * 4)
         packed_bwd = net.packed_bwd(_lib.BWD_DNERF_FUSED)
         mask_per_ray = bits.numel() // N
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
