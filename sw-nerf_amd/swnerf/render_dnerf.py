@@ -15,6 +15,7 @@ from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coars
 from .model import DirectTemporalNeRF
 
 DEBUG = False
+DNERF_CHUNK_DIV = int(os.environ.get("SWNERF_DNERF_CHUNK_DIV", "2"))   # the D-NeRF backward holds two gradient buffers per chunk
 
 
 def batchify(fn, chunk):
@@ -135,7 +136,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         # holds the 3.8 GB the static backward's chunk does; the GEMMs of a chunk fan out over side streams (model._Fan), which
         # hides most of what an extra chunk used to cost (one atomic epilogue per GEMM).  Round 2 held the whole fine pass in
         # one chunk: 15 GB of gradients, 29.6 GiB peak for a 4096-ray step.
-        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // 2 // rows_per_ray) // 4 * 4)
+        chunk = max(4, (_r.TRAIN_BWD_CHUNK_ROWS // DNERF_CHUNK_DIV // rows_per_ray) // 4 * 4)
         packed_bwd = net.packed_bwd(_lib.BWD_DNERF_FUSED)
         mask_per_ray = bits.numel() // N
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
