@@ -324,6 +324,9 @@ def resample_ops(z_vals, weights, N_importance, u=None):
     """nerf/run.py:394-400,416 on the individual ops, for sample counts beyond the fused pass's LDS slice (the reference
     takes any N_samples): sample_pdf on the mid-points (the HIP op; device tensor ops past 1024 bins), torch.sort of
     cat[z_vals, z_samples], std of the samples.  u None = deterministic (perturb == 0).  -> z_fine [N, S+Ni], z_std [N]"""
+    if z_vals.shape[-1] < 3:
+        # weights[..., 1:-1] is empty: the reference's sample_pdf indexes an empty cdf with -1 and raises (ray.py:113-146)
+        raise ValueError(f"swnerf.render_rays: hierarchical resampling needs N_samples >= 3 (got {z_vals.shape[-1]}); the reference fails there too")
     z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
     z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(u is None), u=u).detach()
     z_fine, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)

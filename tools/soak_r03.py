@@ -49,6 +49,8 @@ with torch.no_grad():
         N = int(rng.choice([1, 2, 3, 5, 37, 256, 1023, 1024, 1025, int(rng.integers(1, 3000))]))
         S = int(rng.choice([2, 3, 7, 32, 33, 64, 100, 256, 257, 300, int(rng.integers(2, 320))]))
         Ni = int(rng.choice([0, 0, 1, 5, 64, 128, 129, 700, 900, int(rng.integers(1, 200))]))
+        if S < 3:
+            Ni = 0                                             # the reference itself cannot resample 2 coarse samples
         kw = dict(white_bkgd=bool(rng.integers(2)), lindisp=bool(rng.integers(2)), perturb=float(rng.integers(2)), pytest=True,
                   raw_noise_std=float(rng.choice([0.0, 0.0, 1.0])), retraw=bool(rng.integers(2)))
         two = bool(rng.integers(2))
