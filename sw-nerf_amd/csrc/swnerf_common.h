@@ -166,6 +166,7 @@ SW_HD float sw_sin_or_cos(float y, int want_cos) {
 // torch.linspace(start, end, steps)[i] in float32 as the ATen CPU kernel computes it:
 // step = (end-start)/(steps-1); i < steps/2 ? fma(step, i, start) : fma(-step, steps-1-i, end)
 SW_HD float sw_linspace(float start, float end, int steps, int i) {
+    if (steps <= 1) return start;                              // torch.linspace(a, b, 1) == [a]  (N_importance = 1)
     const float step = (end - start) / (float)(steps - 1);
     return (i < steps / 2) ? fmaf(step, (float)i, start) : fmaf(-step, (float)(steps - 1 - i), end);
 }
