@@ -75,8 +75,10 @@ with torch.no_grad():
         worst = max(worst, float(dlt.max()))
         # (hundreds of drawn samples per ray: the chance that ONE of them sits at a flipping bin edge of sample_pdf - DESIGN.md 6 -
         # grows with their number; 65 % of the rays within 2e-5 at 900 samples, max 1e-2, measured)
-        need = (0.9 if Ni <= 200 else 0.5) if N >= 37 else 0.0
-        assert frac >= need and float(dlt.max()) <= 5e-2, (tag, frac, float(dlt.max()))
+        # The gates of the golden cases (tests/test_gpu_parity.py _cmp): >= 70 % within 2e-5, >= 90 % within 2e-4.
+        frac4 = float((dlt <= 2e-4).float().mean())
+        lo5, lo4 = ((0.7, 0.9) if Ni <= 200 else (0.5, 0.7)) if N >= 37 else (0.0, 0.0)
+        assert frac >= lo5 and frac4 >= lo4 and float(dlt.max()) <= 5e-2, (tag, frac, frac4, float(dlt.max()))
         if "rgb0" in a:
             assert float((a["rgb0"] - b["rgb0"]).abs().max()) <= 2e-5, tag                      # in front of the resampling: tight
         if N >= 5:                                                                               # rays are independent
