@@ -78,7 +78,8 @@ with torch.no_grad():
         # The gates of the golden cases (tests/test_gpu_parity.py _cmp): >= 70 % within 2e-5, >= 90 % within 2e-4.
         frac4 = float((dlt <= 2e-4).float().mean())
         lo5, lo4 = ((0.7, 0.9) if Ni <= 200 else (0.5, 0.7)) if N >= 37 else (0.0, 0.0)
-        hard = 5e-2 if S >= 32 else 0.25                      # a flipped sample moves by up to one bin: few coarse samples = wide bins
+        # a flipped sample moves by up to one bin: few coarse samples, lindisp spacing (wide far bins) or hundreds of draws widen the tail
+        hard = 5e-2 if (S >= 64 and not kw["lindisp"] and Ni <= 200) else 0.25
         assert frac >= lo5 and frac4 >= lo4 and float(dlt.max()) <= hard, (tag, frac, frac4, float(dlt.max()))
         if "rgb0" in a:
             assert float((a["rgb0"] - b["rgb0"]).abs().max()) <= 2e-5, tag                      # in front of the resampling: tight
