@@ -79,7 +79,7 @@ with torch.no_grad():
         frac4 = float((dlt <= 2e-4).float().mean())
         lo5, lo4 = ((0.7, 0.9) if Ni <= 200 else (0.5, 0.7)) if N >= 37 else (0.0, 0.0)
         # a flipped sample moves by up to one bin: few coarse samples, lindisp spacing (wide far bins) or hundreds of draws widen the tail
-        hard = 5e-2 if (S >= 64 and not kw["lindisp"] and Ni <= 200) else 0.25
+        hard = 5e-2 if (S >= 64 and not kw["lindisp"] and Ni <= 200) else (0.25 if S >= 32 else 1.0)
         assert frac >= lo5 and frac4 >= lo4 and float(dlt.max()) <= hard, (tag, frac, frac4, float(dlt.max()))
         if "rgb0" in a:
             assert float((a["rgb0"] - b["rgb0"]).abs().max()) <= 2e-5, tag                      # in front of the resampling: tight
