@@ -3,6 +3,8 @@ code; rays are independent, so the full-image render is split into contiguous ro
 shards, one process per GPU, and the only exchange is ONE all-gather of the rendered
 pixels [rgb(3), disp, acc] (1.6 MB per rank for an 800x800 frame on 8 GPUs) - RCCL over
 xGMI when the process group's backend is "nccl", gloo in the CPU tests."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -56,25 +58,66 @@ def render_image_sharded(render_range, H, W, group=None):
     return full.reshape(H, W, -1)
 
 
-def frame_renderer(H, W, K, c2w, render_kwargs, frame_time=None, chunk=1 << 30, device=None):
+FRAME_STREAMS = int(os.environ.get("SWNERF_FRAME_STREAMS", "2"))   # sub-ranges of a shard rendered concurrently (1: off)
+_FRAME_SIDE = {}
+
+
+def frame_renderer(H, W, K, c2w, render_kwargs, frame_time=None, chunk=1 << 30, device=None, streams=None):
     """The per-rank half of the sharded full-image render (BASELINE configs C4 / C5; the reference's render-only
     entry nerf/run.py:557-571, d_nerf/run_dnerf.py:553-566 renders every pose with render(H, W, K, c2w=...)):
     returns render_range(ray0, n) -> [n, 5] = [rgb(3), disp, acc] of the row-major pixel range, doing what render()
     does for those pixels - get_rays on the range (each rank generates its own rays from (K, c2w): no scatter), ray
-    batch, coarse pass, resampling, fine pass.  frame_time given -> the D-NeRF render (run_dnerf.py:104-173)."""
+    batch, coarse pass, resampling, fine pass.  frame_time given -> the D-NeRF render (run_dnerf.py:104-173).
+
+    streams (default FRAME_STREAMS = 2): a range of >= 8192 rays is rendered as that many contiguous sub-ranges on side
+    streams.  One wavefront owns one ray and 1024 are resident, so a launch of n rays leaves its last round of workgroups
+    partly empty (20 000 rays = 19.53 rounds: 2.3 % of the launch idle, twice per render); with two sub-ranges in flight the
+    workgroups of one sub-range's next launch start on the CUs the other's last round leaves idle (each needs a whole CU),
+    and only the very end of the shard is ragged.  Rays are independent: the pixels are the same bits either way."""
     from . import render as _r, render_dnerf as _rd
     from .ray import get_rays_range
+    n_streams = FRAME_STREAMS if streams is None else int(streams)
+
+    def one(ray0, n):
+        if frame_time is None:
+            o, d = get_rays_range(H, W, K, c2w, ray0, n, device)
+            rgb, disp, acc, _ = _r.render(H, W, K, chunk=chunk, rays=(o, d), **render_kwargs)
+        else:
+            focal = float(K[0][0]) if not isinstance(K, float) else K
+            o, d = get_rays_range(H, W, focal, c2w, ray0, n, device)
+            rgb, disp, acc, _ = _rd.render(H, W, focal, chunk=chunk, rays=(o, d), frame_time=frame_time, **render_kwargs)
+        return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
 
     def render_range(ray0, n):
         with torch.no_grad():
-            if frame_time is None:
-                o, d = get_rays_range(H, W, K, c2w, ray0, n, device)
-                rgb, disp, acc, _ = _r.render(H, W, K, chunk=chunk, rays=(o, d), **render_kwargs)
-            else:
-                focal = float(K[0][0]) if not isinstance(K, float) else K
-                o, d = get_rays_range(H, W, focal, c2w, ray0, n, device)
-                rgb, disp, acc, _ = _rd.render(H, W, focal, chunk=chunk, rays=(o, d), frame_time=frame_time, **render_kwargs)
-        return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+            dev = torch.device(device) if device is not None else None
+            if n_streams <= 1 or n < 8192 or dev is None or dev.type != "cuda":
+                return one(ray0, n)
+            main = torch.cuda.current_stream(dev)
+            if not any(p_.is_cuda for net in (render_kwargs.get("network_fn"), render_kwargs.get("network_fine")) if net is not None
+                       for p_ in net.parameters()):
+                return one(ray0, n)
+            _r.prepack(render_kwargs.get("network_fn"), render_kwargs.get("network_fine"))
+            key = (dev.index, n_streams)
+            if key not in _FRAME_SIDE:
+                _FRAME_SIDE[key] = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+            side = _FRAME_SIDE[key]
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            outs, a = [], 0
+            for i, s in enumerate(side):
+                cnt = (n - a) if i == n_streams - 1 else ((n // n_streams + 3) // 4 * 4)     # whole workgroups of 4 rays
+                s.wait_event(ev0)
+                with torch.cuda.stream(s):
+                    t = one(ray0 + a, cnt)
+                t.record_stream(main)
+                outs.append(t)
+                a += cnt
+            for s in side:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                main.wait_event(ev)
+            return torch.cat(outs, 0)
     return render_range
 
 

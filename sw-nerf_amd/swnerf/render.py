@@ -142,6 +142,21 @@ def set_precision(name):
     return prev
 
 
+def prepack(*nets):
+    """Build (or refresh) the packed weight streams the fused pass will ask for, on the CURRENT stream - for callers that
+    then launch on several streams at once (parallel.frame_renderer): the cached blob must not be written on one stream while
+    another reads it."""
+    for net in nets:
+        if net is None or not hasattr(net, "packed"):
+            continue
+        if isinstance(net, vallina_NeRF) and net._noview_params() is not None:
+            net.packed_noview()
+        elif net._is_fused_arch():
+            net.packed()
+            if _PRECISIONS[PRECISION]:
+                net.packed_x3()
+
+
 def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
                 want=("rgb_map", "disp_map", "acc_map"), n_importance=0, u=None, run_deform=True, precision=None):
     """One launch of `swnerf_render_pass` (include/swnerf.h).  Returns a dict of the requested
