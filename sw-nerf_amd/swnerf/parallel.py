@@ -58,7 +58,7 @@ def render_image_sharded(render_range, H, W, group=None):
     return full.reshape(H, W, -1)
 
 
-FRAME_STREAMS = int(os.environ.get("SWNERF_FRAME_STREAMS", "2"))   # sub-ranges of a shard rendered concurrently (1: off)
+FRAME_STREAMS = int(os.environ.get("SWNERF_FRAME_STREAMS", "1"))   # sub-ranges of a shard rendered concurrently (1: off, the default)
 _FRAME_SIDE = {}
 
 
@@ -69,11 +69,13 @@ def frame_renderer(H, W, K, c2w, render_kwargs, frame_time=None, chunk=1 << 30, 
     does for those pixels - get_rays on the range (each rank generates its own rays from (K, c2w): no scatter), ray
     batch, coarse pass, resampling, fine pass.  frame_time given -> the D-NeRF render (run_dnerf.py:104-173).
 
-    streams (default FRAME_STREAMS = 2): a range of >= 8192 rays is rendered as that many contiguous sub-ranges on side
-    streams.  One wavefront owns one ray and 1024 are resident, so a launch of n rays leaves its last round of workgroups
+    streams > 1 (default FRAME_STREAMS = 1: off): a range of >= 8192 rays is rendered as that many contiguous sub-ranges on
+    side streams.  One wavefront owns one ray and 1024 are resident, so a launch of n rays leaves its last round of workgroups
     partly empty (20 000 rays = 19.53 rounds: 2.3 % of the launch idle, twice per render); with two sub-ranges in flight the
-    workgroups of one sub-range's next launch start on the CUs the other's last round leaves idle (each needs a whole CU),
-    and only the very end of the shard is ragged.  Rays are independent: the pixels are the same bits either way."""
+    workgroups of one sub-range's next launch can start on the CUs the other's last round leaves idle.  Measured round 3
+    (`profiles/r03/frame_streams.md`): +0.25 % on the C4 shard, nothing on the C5 shard, three streams slower - the overlap
+    puts two nets' weight streams (4.8 MB) into the 4 MB L2s at once, which costs what the filled tail gains.  Kept as an
+    option; rays are independent, so the pixels are the same bits either way (tests/test_gpu_sharded.py)."""
     from . import render as _r, render_dnerf as _rd
     from .ray import get_rays_range
     n_streams = FRAME_STREAMS if streams is None else int(streams)

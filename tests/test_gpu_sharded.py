@@ -61,9 +61,9 @@ def test_c4_shard_80000_rays(dev):
     half = (hi - lo) // 2
     both = torch.cat([rr(lo, half), rr(lo + half, hi - lo - half)], 0)
     assert torch.equal(both.nan_to_num(-1.0), px.nan_to_num(-1.0))
-    # the shard is rendered as two concurrent sub-ranges on side streams by default (so that one sub-range's next launch fills the
-    # CUs the other's ragged last round leaves idle); one stream, three streams: the same bits
-    for ns in (1, 3):
+    # the option to render the shard as concurrent sub-ranges on side streams (so that one sub-range's next launch fills the
+    # CUs the other's ragged last round leaves idle): two streams, three streams: the same bits
+    for ns in (2, 3):
         assert torch.equal(parallel.frame_renderer(H, W, K, c2w, kw, device=dev, streams=ns)(lo, hi - lo).nan_to_num(-1.0), px.nan_to_num(-1.0))
     # the reference's chunk (utils.py:33, 32768 rays) through batchify_rays gives the same pixels
     rr_chunked = parallel.frame_renderer(H, W, K, c2w, kw, chunk=1024 * 32, device=dev)
@@ -119,8 +119,8 @@ def test_c5_shard_20000_rays_dnerf(dev):
         assert torch.equal(rr(lo, hi - lo).nan_to_num(-1.0), px.nan_to_num(-1.0))
         both = torch.cat([rr(lo, 7000), rr(lo + 7000, hi - lo - 7000)], 0)
         assert torch.equal(both.nan_to_num(-1.0), px.nan_to_num(-1.0))
-        one_stream = parallel.frame_renderer(H, W, K, c2w, kw, frame_time=tv, device=dev, streams=1)(lo, hi - lo)
-        assert torch.equal(one_stream.nan_to_num(-1.0), px.nan_to_num(-1.0))       # the default renders two sub-ranges concurrently
+        two_streams = parallel.frame_renderer(H, W, K, c2w, kw, frame_time=tv, device=dev, streams=2)(lo, hi - lo)
+        assert torch.equal(two_streams.nan_to_num(-1.0), px.nan_to_num(-1.0))      # two sub-ranges rendered concurrently: the same bits
         rb = O.make_ray_batch(o.reshape(-1, 3)[lo + sel], d.reshape(-1, 3)[lo + sel], 2., 6., frame_time=tv)
         with torch.no_grad():
             ref = O.render_rays_dnerf(rb, sd, 64, 128, white_bkgd=True)
