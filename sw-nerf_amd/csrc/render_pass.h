@@ -122,8 +122,10 @@ __device__ __forceinline__ void pass_startup(const PassDev& P, const float* w0, 
 // host side: fill the start-up fields for a launch of `grid_x` workgroups whose pass streams `steps` weight steps per tile.
 // SWNERF_WARM / SWNERF_SKEW (experiments: tools/probe_small_batch.py) override the defaults.
 static inline void pass_startup_args(PassDev& P, unsigned grid_x, int steps) {
-    static const int env_warm = [] { const char* e = getenv("SWNERF_WARM"); return e ? atoi(e) : 1; }();
-    static const int env_skew = [] { const char* e = getenv("SWNERF_SKEW"); return e ? atoi(e) : 2; }();
+    // read per launch (two getenv calls, ~100 ns): tests flip them between launches to show that the shaping changes no bit
+    const char* ew = getenv("SWNERF_WARM");
+    const char* es = getenv("SWNERF_SKEW");
+    const int env_warm = ew ? atoi(ew) : 1, env_skew = es ? atoi(es) : 2;
     const unsigned first_round = grid_x < 256u ? grid_x : 256u;      // one workgroup per CU is resident
     P.warm_blocks = (int)(first_round / 8u);
     P.warm_steps = (env_warm && P.warm_blocks > 0) ? steps + SW_TAIL : 0;

@@ -511,6 +511,25 @@ def test_c3_ndc_batch_full_size_properties(sw, dev, nets):
     _cmp(got, ref, ["rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"], "C3 full size", psnr_min=86.0, hard=4e-2)
 
 
+def test_startup_shaping_changes_no_bit(sw, dev, nets, monkeypatch):
+    """The start-up shaping of a launch (csrc/render_pass.h pass_startup: L2 warm-up of the weight stream by LDS-DMA into a
+    junk slot that later holds the parked encodings, waves starting 0..15 ring steps apart) is timing only: every output of
+    the fused passes - static, D-NeRF, without view directions is covered by the soak - is bit-identical with it off."""
+    q, qd = _query(sw), _query_d(sw)
+    g = cases.g7_inputs(n=1027, seed=77)                       # one full round of waves and a ragged workgroup
+    outs = {}
+    for warm, skew in (("0", "0"), ("1", "2"), ("1", "1"), ("0", "2")):
+        monkeypatch.setenv("SWNERF_WARM", warm)
+        monkeypatch.setenv("SWNERF_SKEW", skew)
+        a = sw.render.render_rays(_rb(g, dev), nets["coarse"], q, 64, retraw=True, N_importance=128, network_fine=nets["fine"], white_bkgd=True)
+        b = sw.render_dnerf.render_rays(_rb(g, dev, 0.5)[:300], nets["dn"], qd, 64, retraw=True, N_importance=128, white_bkgd=True)
+        outs[(warm, skew)] = [v.clone() for v in a.values()] + [v.clone() for v in b.values()]
+    base = outs[("0", "0")]
+    for k, v in outs.items():
+        for x, y in zip(base, v):
+            assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), k
+
+
 def test_render_full_image_c2w_and_chunking(sw, dev, nets):
     """render(c2w=...) on a small frame == oracle; chunked == unchunked bit for bit."""
     K, c2w = cases.synth.lego_camera(24, 40, theta=10.0)
