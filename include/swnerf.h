@@ -62,6 +62,10 @@ int swnerf_pack_net(int kind, const float* const* params /*HOST*/, int L_pos, in
  *   [16,17]  output_linear.{weight,bias}        [out_ch,256], out_ch = 4 or 5 (nerf/run.py:231)
  * packed: swnerf_packed_floats(SWNERF_NET_NOVIEW) floats. */
 int swnerf_pack_net_noview(const float* const* params /*HOST*/, int L_pos, int out_ch, float* packed, void* stream);
+/* vallina_NeRF.forward for that net (model.py:39-47, 59-60) on embedded rows: x [M, ldx] whose first 3(1+2 L_pos) columns are
+ * gamma(x) -> out [M, out_ch] = output_linear(h).  The op-by-op form (run_network, nerf/run.py:73-87); the fused render pass
+ * takes the same packed blob with kind SWNERF_NET_NOVIEW. */
+int swnerf_mlp_forward_noview(const float* packed, const float* x, int64_t M, int ldx, int L_pos, int out_ch, float* out, void* stream);
 
 /* ---- ray.py -------------------------------------------------------------------------- */
 

@@ -192,3 +192,53 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     else hipLaunchKernelGGL(mlp_forward_kernel<false>, grid, block, lds, st, P);
     return sw_check(hipGetLastError(), "mlp_forward launch");
 }
+
+// model.forward(x) for the net WITHOUT view directions (SWNERF_NET_NOVIEW; model.py:39-47, 59-60): x [M, C_pos] (any
+// further columns of a wider row are ignored, like torch.split's second half with input_ch_views = 0), out [M, out_ch].
+struct MlpNoviewDev { const float* x; int64_t M; int C; int Lp; const float* w0; const float* b0; int nbias; int out_ch; float* out; };
+
+__global__ void __launch_bounds__(256, 1) mlp_forward_noview_kernel(MlpNoviewDev P) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float lds_bias[];
+    float* lds_ring = lds_bias + SW_LDS_BIAS_FLOATS + wv * SW_LDS_RING_FLOATS;
+    float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    bias_to_lds(lds_bias, P.b0, P.nbias);
+    if (tile * 32 >= P.M) return;
+    const int64_t row = tile * 32 + j;
+    const bool live = row < P.M;
+    const float* xr = P.x + (live ? row : P.M - 1) * P.C;
+    f32x16 emb[2], in[8], out[8];
+    float head[3];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        const int col = sw_pos_col(a, h, P.Lp);
+        emb[a >> 4][a & 15] = (col >= 0) ? xr[col] : 0.f;
+    }
+    WStream ws;
+    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    trunk_pass<false, false, false, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
+    float o5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    head_valu_rt<8>(in, ws, P.out_ch, o5);
+    if (live && h == 0) {
+        float* o = P.out + row * P.out_ch;
+        o[0] = o5[0] + ws.bias[0]; o[1] = o5[1] + ws.bias[1]; o[2] = o5[2] + ws.bias[2]; o[3] = o5[3] + ws.bias[3];
+        if (P.out_ch == 5) o[4] = o5[4] + ws.bias[4];
+    }
+}
+
+// vallina_NeRF.forward on embedded rows for use_viewdirs=False (model.py:39-47, 59-60): x [M, ldx >= C_pos] -> out [M, out_ch]
+extern "C" int swnerf_mlp_forward_noview(const float* packed, const float* x, int64_t M, int ldx, int L_pos, int out_ch, float* out, void* stream) {
+    if (M == 0 && packed) return 0;
+    if (!packed || !x || !out || M < 0) return sw_fail(SWNERF_E_ARG, "mlp_forward_noview: NULL pointer or negative M");
+    if (L_pos < 0 || L_pos > 10) return sw_fail(SWNERF_E_UNSUPP, "mlp_forward_noview: %d position bands exceed 10", L_pos);
+    if (ldx < 3 * (1 + 2 * L_pos)) return sw_fail(SWNERF_E_ARG, "mlp_forward_noview: rows of %d floats cannot hold %d embedded columns", ldx, 3 * (1 + 2 * L_pos));
+    MlpNoviewDev P;
+    P.x = x; P.M = M; P.C = ldx; P.Lp = L_pos; P.out_ch = out_ch; P.out = out;
+    int two = 0;
+    int rc = stream_ptrs_noview(packed, out_ch, &P.w0, &P.b0, &P.nbias, &two);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_forward_noview_kernel, dim3((unsigned)((M + 127) / 128)), dim3(256), SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "mlp_forward_noview launch");
+}

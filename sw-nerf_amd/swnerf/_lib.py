@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libswnerf_hip.so")
 
 NET_CANON, NET_DNERF, NET_NOVIEW = 0, 1, 2
 
-EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net", "swnerf_pack_net_noview",
+EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swnerf_pack_net", "swnerf_pack_net_noview", "swnerf_mlp_forward_noview",
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_sample_coarse", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
@@ -61,6 +61,7 @@ def lib():
     L.swnerf_packed_floats.argtypes = [c_int]
     L.swnerf_pack_net.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_pack_net_noview.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_mlp_forward_noview.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]
     L.swnerf_get_rays.argtypes = [c_int, c_int, c_double, c_double, c_double, c_double, c_int,
                                   POINTER(ctypes.c_float), c_int64, c_int64, c_void_p, c_void_p, c_void_p]
     L.swnerf_ndc_rays.argtypes = [c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int64,

@@ -517,11 +517,23 @@ class vallina_NeRF(nn.Module, _PackedMixin):
 
     def forward(self, x):
         if not self._is_fused_arch():
+            if self._noview_params() is not None and not self._wants_grad() and isinstance(x, torch.Tensor) and x.is_cuda:
+                return self._forward_noview(x)           # use_viewdirs=False at 8x256: the register-resident trunk + output_linear heads
             from .generic import canonical_forward
             return canonical_forward(self, x)
         if self._wants_grad():
             return self._forward_train(x)
         return self._forward_hip(x)[0]
+
+    def _forward_noview(self, x):
+        packed, Lp, out_ch = self.packed_noview()
+        x = _lib.dev_f32(x, "x", self.input_ch + self.input_ch_views)
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, x.shape[-1])
+        out = torch.empty((flat.shape[0], out_ch), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().swnerf_mlp_forward_noview(_lib.ptr(packed), _lib.ptr(flat), flat.shape[0], flat.shape[1], Lp, out_ch,
+                                                        _lib.ptr(out), _lib.stream_of(x)), "mlp_forward_noview")
+        return out.reshape(*lead, out_ch)
 
 
 class NeRFOriginal(nn.Module, _PackedMixin):

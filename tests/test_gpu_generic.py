@@ -185,6 +185,12 @@ def test_fused_pass_without_viewdirs_golden(dev, golden):
         b = render.render_rays(rb8.to(dev), nets[0], opaque, 64, N_importance=0, white_bkgd=True, retraw=True)
         close(a["raw"], b["raw"], atol=2e-4, rtol=1e-4, what="fused vs generic raw")
         close(a["rgb_map"], b["rgb_map"], atol=2e-5, what="fused vs generic rgb")
+        # module.forward on embedded rows (run_network's op path, nerf/run.py:73-87) runs the same trunk + heads as one kernel
+        # (swnerf_mlp_forward_noview) and equals the layer-by-layer generic path of the same module
+        from swnerf.generic import canonical_forward
+        xe = embed_fn(torch.from_numpy(cases.g11_inputs()["pts"]).to(dev))
+        close(nets[0](xe), canonical_forward(nets[0], xe), atol=2e-5, rtol=1e-5, what="module.forward: fused vs layer by layer")
+        assert nets[0](xe.reshape(3, 100, 63)).shape == (3, 100, 5) and nets[0](xe[:33]).shape == (33, 5)
         # 4-channel head, empty batch, and the wrong column count is an error of the C ABI, not a wrong image
         net4 = model.vallina_NeRF(**dict(cases.G12_NET, output_ch=4))
         sd4 = {k: v for k, v in cases.g12_weights()[0].items()}

@@ -47,7 +47,7 @@ def test_mfma_kernels_isa(asm):
         steps = 64 + 256 + 64 + 256 + 144 + (96 if "kernelILb1" in name else 0)
         if "query_points" in name:
             steps = 64 + 256 + 64 + 256 + 144
-        if "render_pass_kernelILb0ELb0ELi0ELb0EE" in name:      # VIEWS = false: the trunk alone - L0 (64), trunk body (256), skip-emb (64)
+        if "render_pass_kernelILb0ELb0ELi0ELb0EE" in name or "mlp_forward_noview" in name:   # no view branch: L0 (64), trunk body (256), skip-emb (64)
             steps = 64 + 256 + 64
         if "mlp_backward_dx" in name:              # RGB^T (16) VIEWS^T (128) FEAT^T (256) + the L7..L1 loop body (256)
             steps = 16 + 128 + 256 + 256          # <true>: + the gamma(x) columns of pts_linears.5 and .0 (64 each)
@@ -73,7 +73,7 @@ def test_mfma_kernels_isa(asm):
         # the fused pass pulls the weight stream into L2 at kernel start with one more static DMA site (render_pass.h pass_startup)
         warm = 1 if "render_pass_kernel" in name else 0
         assert dma == steps + (16 if training else 8) + masks + warm, (name, dma)
-    assert len(seen) == 15
+    assert len(seen) == 16
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)
         assert m, name
