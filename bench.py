@@ -499,9 +499,9 @@ def worker(args):
         rays_o, rays_d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
         n_local, rays_per_step, scaling = N_RAND, world * N_RAND, "weak"
 
-        def step():
+        def local():                                     # this rank's part of a step: no collective
             rgb, disp, acc, _ = render.render(H, W, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kw)
-            return gather(torch.cat([rgb, disp[:, None], acc[:, None]], -1))
+            return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
     else:
         lo, hi = synth.shard_range(H * W, world, rank)
         n_local, rays_per_step, scaling = hi - lo, H * W, "strong"
@@ -509,8 +509,11 @@ def worker(args):
             raise SystemExit(f"[bench] {cfg}: {H * W} rays do not split evenly over {world} ranks")
         render_range = parallel.frame_renderer(H, W, K, c2w, kw, frame_time=sc["frame_time"], device=dev)
 
-        def step():
-            return gather(render_range(lo, hi - lo))
+        def local():
+            return render_range(lo, hi - lo)
+
+    def step():
+        return gather(local())
 
     def fence():
         finish()
@@ -524,9 +527,10 @@ def worker(args):
         # clock pre-warm (untimed, before the W warm-up steps, reported as config.clock_prewarm_s): the scene set-up above is
         # seconds of GPU idle, and the first milliseconds of GPU work after an idle spell run at a reduced clock
         # (profiles/r03/clock_ramp.md); W = 5 steps of 8 ms do not reliably cover that
+        # - WITHOUT the collective: the number of pre-warm renders differs from rank to rank, collectives must not
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < PREWARM_S:
-            step()
+            local()
             torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
             step()
