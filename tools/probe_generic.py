@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Throughput of the generic (layer-by-layer) path: a use_viewdirs=False 8x256 net on [M,63] embedded rows, and the
-end-to-end render (4096 rays, 64+128) without view directions, against the fused path with view directions."""
+"""Throughput of the generic (layer-by-layer) path - the nets the register-resident kernels are not built for: forward of
+a D=8 / W=256 / skips=[2,5] net with view directions and of a D=6 / W=384 net on embedded rows, their training step
+(forward + backward through swnerf_linear / swnerf_gemm_nn / swnerf_gemm_tn), and the use_viewdirs=False 8x256 net's
+training forward+backward.  SWNERF_GENERIC_GEMM_OLD=1 selects the round-2 64x64 GEMM kernel for comparison."""
 import os
 import sys
 import time
@@ -8,36 +10,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     sys.path.insert(0, p)
 import torch
-from swnerf import synth, model, embedder, render
+from swnerf import model
 
 dev = torch.device("cuda:0")
-net = model.vallina_NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False).to(dev).eval()
 M = 262144
-x = torch.randn((M, 63), device=dev)
-with torch.no_grad():
-    net(x); net(x)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        net(x)
-    torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 5
-macs = 63 * 256 + 4 * 256 * 256 + 319 * 256 + 2 * 256 * 256 + 256 * 5
-print(f"| generic MLP forward, {M} rows | {dt * 1e3:.2f} ms | {2 * macs * M / dt / 1e12:.1f} TFLOP/s |")
-embed_fn, _ = embedder.get_embedder(10, 3, 0)
-embeddirs_fn = None
-q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
-K, c2w = synth.lego_camera(800, 800)
-o, d = synth.pick_rays(800, 800, K, c2w, 4096, 2)
-rays = (torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
-kw = dict(ndc=False, near=2., far=6., use_viewdirs=False, network_fn=net, network_query_fn=q, N_samples=64, N_importance=128, network_fine=None,
-          white_bkgd=True, perturb=0., raw_noise_std=0.)
-with torch.no_grad():
-    render.render(800, 800, K, rays=rays, **kw)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        render.render(800, 800, K, rays=rays, **kw)
-    torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 3
-print(f"| render(), 4096 rays x (64+128), use_viewdirs=False (generic path) | {dt * 1e3:.1f} ms | {4096 / dt:,.0f} rays/s |")
+print(f"SWNERF_GENERIC_GEMM_OLD={os.environ.get('SWNERF_GENERIC_GEMM_OLD', '(unset)')}  M={M}")
+print("| net | what | ms | TFLOP/s (2 x MACs x rows; x3 for a training step) |")
+print("|---|---|---|---|")
+for name, kw in (("D=8 W=256 skips=[2,5] use_viewdirs", dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[2, 5], use_viewdirs=True)),
+                 ("D=6 W=384 skips=[3] use_viewdirs", dict(D=6, W=384, input_ch=63, input_ch_views=27, output_ch=5, skips=[3], use_viewdirs=True)),
+                 ("D=8 W=256 skips=[4] use_viewdirs=False (training runs here)", dict(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False))):
+    net = model.vallina_NeRF(**kw).to(dev)
+    x = torch.randn((M, kw["input_ch"] + kw["input_ch_views"]), device=dev)
+    W, D = kw["W"], kw["D"]
+    macs = kw["input_ch"] * W + sum((W + kw["input_ch"] if (i - 1) in kw["skips"] else W) * W for i in range(1, D))
+    macs += (W * W + W + (W + kw["input_ch_views"]) * (W // 2) + (W // 2) * 3) if kw["use_viewdirs"] else W * kw["output_ch"]
+    for what, grad in (("forward", False), ("forward + backward", True)):
+        if not grad and not net._is_fused_arch() and net._noview_params() is not None:
+            continue                                  # that forward runs on the register-resident kernel
+        net.train(grad)
+
+        def f():
+            if grad:
+                for p_ in net.parameters():
+                    p_.grad = None
+                net(x).sum().backward()
+            else:
+                with torch.no_grad():
+                    net(x)
+        f(); f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"| {name} | {what} | {dt * 1e3:.2f} | {(3 if grad else 1) * 2 * macs * M / dt / 1e12:.1f} |")
