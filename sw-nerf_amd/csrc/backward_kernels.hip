@@ -142,8 +142,13 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
     __shared__ __attribute__((aligned(16))) float Bs[GT_SLAB][256];
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int obase = 128 * (blockIdx.y & 1);        // which half of the (up to) 256 output rows
-    const int i0 = 256 * (blockIdx.y >> 1);
+    // grid.y = (256-column blocks of C) x (halves of its up to 256 rows: 2 only when No > 128 - the launch's formula).
+    // (Round 2 decoded y as if the factor were always 2: with No <= 128 and Ni > 256 - views_linears.0 of a W = 256 net on
+    // the generic path, 128 x 283 - block y = 1 then read A 128 columns to the right of its rows and the columns of C past
+    // 256 were never accumulated; found in round 3 by a fault on operands whose allocation ended with their last row.)
+    const int nsplit = P.No > 128 ? 2 : 1;
+    const int obase = 128 * (blockIdx.y % nsplit);   // which half of the (up to) 256 output rows
+    const int i0 = 256 * (blockIdx.y / nsplit);
     const int o0 = 32 * (wv & 3), ih = 128 * (wv >> 2);
     const int nb = max(0, min(4, (P.Ni - i0 - ih + 31) / 32));
     const bool strip = (obase + o0) < P.No && nb > 0;
@@ -245,7 +250,7 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
             if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
-    if (P.bias && (blockIdx.y >> 1) == 0 && ih == 0) {
+    if (P.bias && i0 == 0 && ih == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         if (he == 0 && (obase + o0 + ie) < P.No) atomicAdd(P.bias + obase + o0 + ie, bsum);
     }

@@ -492,6 +492,9 @@ def test_gemm_tn_256x256_dma_path(dev, M):
     (4, 128, 0, 2304, 4, 2432),       # rgb_linear in its 4-row form: d raw x the view hidden layer
     (4, 256, 0, 1792, 4, 2432),       # _time_out in its 4-row form
     (8, 100, 4, 8, 16, 128),          # not a shape of the step: widths that are no multiples of 32
+    (128, 283, 0, 0, 128, 283),       # views_linears.0 of a W = 256 net on the GENERIC path: <= 128 rows of C, more than 256 columns -
+    (64, 300, 0, 0, 64, 300),         # round 2 decoded the grid of this case wrongly (columns past 256 never accumulated, A read out of its rows)
+    (256, 319, 0, 0, 256, 319),       # a skip layer on the generic path: both halves of C's rows, two column blocks
 ])
 @pytest.mark.parametrize("M", [4096, 50000 + 7])
 def test_gemm_tn_skinny_shapes(dev, M, No, Ni, a_col, b_col, lda, ldb):

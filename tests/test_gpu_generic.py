@@ -205,6 +205,32 @@ def test_fused_pass_without_viewdirs_golden(dev, golden):
             render.render_pass(torch.zeros((4, 11), device=dev), nets[0], 64)
 
 
+def test_generic_training_w256_with_viewdirs(dev):
+    """A W = 256 net WITH view directions on the generic path (skips other than [4]): views_linears.0 is 128 x 283 - at most
+    128 rows of C and more than 256 columns, the weight-gradient shape whose grid round 2 decoded wrongly (the gradient of the
+    view-direction columns stayed zero).  Every parameter gradient against torch autograd through the CPU oracle."""
+    import swnerf.model as model
+    kw = dict(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[2, 5], use_viewdirs=True)
+    sd_np = cases.generic_state_dict(1190, alpha_bias=-0.5, **kw)
+    net = model.vallina_NeRF(**kw)
+    net.load_state_dict({k: T(v) for k, v in sd_np.items()}, strict=True)
+    net = net.to(dev).train()
+    assert not net._is_fused_arch()
+    g = cases.g11_inputs()
+    x = _embedded(dev, kw, g)
+    G = T(np.random.default_rng(13).standard_normal((x.shape[0], 4)).astype(np.float32))
+    with torch.enable_grad():
+        (net(x) * G.to(dev)).sum().backward()
+        sd = {k: v.clone().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
+        (O.generic_mlp(sd, x.cpu(), kw["D"], kw["skips"], kw["input_ch"], kw["input_ch_views"], True) * G).sum().backward()
+    for k, p in net.named_parameters():
+        rg = sd[k].grad
+        assert float(rg.abs().max()) > 0, k
+        assert float((p.grad.cpu() - rg).abs().max()) <= 3e-4 * float(rg.abs().max()), f"{k}: {float((p.grad.cpu() - rg).abs().max()):.3e} of {float(rg.abs().max()):.3e}"
+    wg = net.views_linears[0].weight.grad
+    assert float(wg[:, 256:].abs().max()) > 0            # the view-direction columns
+
+
 def test_generic_training_matches_autograd(dev):
     """loss.backward() through the generic path: every parameter gradient of a use_viewdirs=False net and of the D=4
     DirectTemporalNeRF (incl. the gradient through gamma(x + dx)) vs torch autograd through the CPU oracle."""
