@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     sys.path.insert(0, p)
 CASES = ["rays", "embed", "pass_static", "pass_dnerf", "pass_noview", "raw2outputs", "sample_pdf", "mlp_static", "mlp_dnerf", "mlp_noview",
-         "query", "sample_coarse", "train_static", "train_dnerf"]
+         "query", "sample_coarse", "train_static", "train_dnerf", "pass_x3_static", "pass_x3_dnerf"]
 if len(sys.argv) < 2 or sys.argv[1] == "list":
     print(" ".join(CASES))
     sys.exit(0)
@@ -77,7 +77,10 @@ with torch.no_grad():
         assert out.shape == (4 * N, 63) and bool(torch.isfinite(out).all())
         t = embedtime_fn(tight(torch.rand((8 * N, 1), device=dev)))
         assert t.shape == (8 * N, 21)
-    elif case in ("pass_static", "pass_noview", "pass_dnerf"):
+    elif case in ("pass_static", "pass_noview", "pass_dnerf", "pass_x3_static", "pass_x3_dnerf"):
+        if "x3" in case:
+            render.set_precision("bf16x3")                   # the opt-in bf16x3 pass (csrc/mlp_core_x3.h)
+            case = case.replace("_x3", "")
         net = {"pass_static": static_net, "pass_noview": noview_net, "pass_dnerf": dnerf_net}[case]()
         rb = ray_batch({"pass_static": 11, "pass_noview": 8, "pass_dnerf": 12}[case])
         n = N
@@ -153,4 +156,4 @@ if case in ("train_static", "train_dnerf"):
         (((rgb - tgt) ** 2).mean() + 0.1 * ex["position_delta"].pow(2).mean()).backward()
         assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in dn.parameters())
 torch.cuda.synchronize()
-print(f"{case}: ok", flush=True)
+print(f"{sys.argv[1]}: ok", flush=True)
