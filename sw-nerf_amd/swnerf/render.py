@@ -567,20 +567,57 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
 
 
+def pipelined_frames(frames, consume):
+    """The host side of render_path, one frame deep: `frames` yields (i, rgb, disp) device tensors as each frame's kernels are
+    ENQUEUED; the frame's pixels go to pinned host memory asynchronously, and `consume(i, rgb_np, disp_np)` - PSNR print, PNG
+    encoding, list append: tens of ms of CPU work per 800x800 frame - runs for frame i-1 while the GPU renders frame i.  (The
+    reference does `rgb.cpu().numpy()` + imageio.imwrite between frames, nerf/run.py:199-213, with the GPU idle meanwhile.)
+    Order and values are the reference's; CPU tensors pass straight through."""
+    pending = None
+
+    def done(item):
+        i, h_rgb, h_disp, ev = item
+        if ev is not None:
+            ev.synchronize()
+        consume(i, h_rgb.numpy(), h_disp.numpy())
+
+    for i, rgb, disp in frames:
+        if rgb.is_cuda:
+            h_rgb = torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True)
+            h_disp = torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True)
+            h_rgb.copy_(rgb, non_blocking=True)
+            h_disp.copy_(disp, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(rgb.device))
+        else:
+            h_rgb, h_disp, ev = rgb, disp, None
+        if pending is not None:
+            done(pending)
+        pending = (i, h_rgb, h_disp, ev)
+    if pending is not None:
+        done(pending)
+
+
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
     """nerf/run.py:172-219; with `savedir` every frame is also written as '{:03d}.png' of to8b(rgb) (:210-213)."""
     H, W, focal = hwf
     if render_factor != 0:
         H, W, focal = H // render_factor, W // render_factor, focal / render_factor
     rgbs, disps = [], []
-    for i, c2w in enumerate(render_poses):
-        rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
+
+    def frames():
+        for i, c2w in enumerate(render_poses):
+            rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+            yield i, rgb, disp
+
+    def consume(i, rgb, disp):
+        rgbs.append(rgb)
+        disps.append(disp)
         if gt_imgs is not None and render_factor == 0:                       # nerf/run.py:204-206: PSNR against the ground truth
             gt = gt_imgs[i]
             gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
-            print(-10. * np.log10(np.mean(np.square(rgbs[-1] - gt))))
+            print(-10. * np.log10(np.mean(np.square(rgb - gt))))
         if savedir is not None:
-            write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgbs[-1]))
+            write_png(os.path.join(savedir, '{:03d}.png'.format(i)), to8b(rgb))
+    pipelined_frames(frames(), consume)
     return np.stack(rgbs, 0), np.stack(disps, 0)

@@ -11,7 +11,7 @@ from . import _lib
 from .embedder import to8b
 from .png import write_png
 from .ray import get_rays, sample_pdf, raw2outputs
-from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coarse_z, coarse_pass_resampled
+from .render import fused_plan, render_pass, pack_ray_batch, _rng_inputs, _coarse_z, coarse_pass_resampled, pipelined_frames
 from .model import DirectTemporalNeRF
 
 DEBUG = False
@@ -414,14 +414,20 @@ def render_path(render_poses, render_times, hwf, chunk, render_kwargs, gt_imgs=N
         if save_also_gt:
             os.makedirs(save_dir_gt, exist_ok=True)
     rgbs, disps = [], []
-    for i, (c2w, frame_time) in enumerate(zip(render_poses, render_times)):
-        rgb, disp, acc, _ = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], frame_time=frame_time, **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
+
+    def frames():
+        for i, (c2w, frame_time) in enumerate(zip(render_poses, render_times)):
+            rgb, disp, acc, _ = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], frame_time=frame_time, **render_kwargs)
+            yield i, rgb, disp
+
+    def consume(i, rgb, disp):
+        rgbs.append(rgb)
+        disps.append(disp)
         if savedir is not None:
-            write_png(os.path.join(save_dir_estim, '{:03d}.png'.format(i + i_offset)), to8b(rgbs[-1]))
+            write_png(os.path.join(save_dir_estim, '{:03d}.png'.format(i + i_offset)), to8b(rgb))
             if save_also_gt:
                 gt = gt_imgs[i]
                 gt = gt.cpu().numpy() if isinstance(gt, torch.Tensor) else np.asarray(gt)
                 write_png(os.path.join(save_dir_gt, '{:03d}.png'.format(i + i_offset)), to8b(gt))
+    pipelined_frames(frames(), consume)                 # frame i-1's PNG is encoded while the GPU renders frame i
     return np.stack(rgbs, 0), np.stack(disps, 0)
