@@ -585,12 +585,12 @@ def pipelined_frames(frames, consume):
         if rgb.is_cuda:
             h_rgb = torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True)
             h_disp = torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True)
-            h_rgb.copy_(rgb, non_blocking=True)
-            h_disp.copy_(disp, non_blocking=True)
+            h_rgb.copy_(rgb.detach(), non_blocking=True)
+            h_disp.copy_(disp.detach(), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(rgb.device))
         else:
-            h_rgb, h_disp, ev = rgb, disp, None
+            h_rgb, h_disp, ev = rgb.detach(), disp.detach(), None
         if pending is not None:
             done(pending)
         pending = (i, h_rgb, h_disp, ev)
