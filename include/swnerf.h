@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 104
+#define SWNERF_VERSION 105
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -292,6 +292,21 @@ int swnerf_render_pass_backward(const float* packed_bwd, const float* bits, cons
                                 int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb /*[N,3]*/,
                                 const float* g_disp /*[N]*/, const float* g_acc /*[N]*/, const float* g_raw /*[N,S,4] or NULL*/,
                                 float* grad, float* d_raw, void* stream);
+/* The same pair for the net WITHOUT view directions (SWNERF_NET_NOVIEW; use_viewdirs=False is the reference's argparse
+ * default, nerf/run.py:461, and its create_nerf then builds output_ch = 5 when N_importance > 0, nerf/run.py:231):
+ * swnerf_render_pass_train takes kind SWNERF_NET_NOVIEW with an 8-column ray batch (raw is [N,S,out_ch]; act holds h0..h7
+ * in its first 2048 columns; xs gamma(x) in its first 64 slots), and this backward is its counterpart: packed_bwd =
+ * swnerf_pack_net_bwd_noview (pts_linears.7..1 transposed + output_linear.weight), raw / g_raw [N,S,out_ch], and d_raw8
+ * [rows, 8] = d raw in columns 0..out_ch-1, zeros behind - the 16-byte aligned A operand of output_linear's weight-
+ * gradient GEMM (swnerf_gemm_tn with No = 8).  grad: d pre-activation of pts_linears.0..7 in columns 0..2047. */
+size_t swnerf_packed_bwd_noview_floats(void);
+int swnerf_pack_net_bwd_noview(const float* const* params /*HOST; as swnerf_pack_net_noview*/, int L_pos, int out_ch,
+                               float* packed_bwd, void* stream);
+int swnerf_render_pass_backward_noview(const float* packed_bwd, const float* bits, const float* raw /*[N,S,out_ch]*/,
+                                       const float* z_vals /*[N,S]*/, const float* ray_batch, int cols, const float* noise,
+                                       int64_t n_rays, int n_samples, int white_bkgd, int out_ch, const float* g_rgb /*[N,3]*/,
+                                       const float* g_disp /*[N]*/, const float* g_acc /*[N]*/,
+                                       const float* g_raw /*[N,S,out_ch] or NULL*/, float* grad, float* d_raw8, void* stream);
 /* The same pair for DirectTemporalNeRF at t != 0 (model.py:128-151; the loss of d_nerf/run_dnerf.py:690-725 puts
  * gradients on the image AND on position_delta).  No resampling in the training pass (n_importance must be 0: the
  * one-model configuration's coarse pass is a no_grad inference pass, run_dnerf.py:417-421).  args->dx (position_delta

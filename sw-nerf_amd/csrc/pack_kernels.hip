@@ -272,6 +272,27 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
     return pk.rc;
 }
 
+// The dX chain's stream of the net without view directions: pts_linears.7 .. .1 transposed (trunk columns), then
+// output_linear.weight rows as bias-style tiles.  params as swnerf_pack_net_noview.
+extern "C" size_t swnerf_packed_bwd_noview_floats(void) { return (size_t)SW_NVBWD_FLOATS; }
+extern "C" int swnerf_pack_net_bwd_noview(const float* const* params, int L_pos, int out_ch, float* packed_bwd, void* stream) {
+    if (!params || !packed_bwd) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: NULL pointer");
+    if (L_pos < 0 || L_pos > 10) return sw_fail(SWNERF_E_UNSUPP, "pack_net_bwd_noview: %d position bands exceed 10", L_pos);
+    if (out_ch < 4 || out_ch > SW_NOVIEW_MAX_OUT) return sw_fail(SWNERF_E_UNSUPP, "pack_net_bwd_noview: output_ch %d (4 or 5)", out_ch);
+    for (int i = 0; i < 18; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: params[%d] is NULL", i);
+    const int Cpos = 3 * (1 + 2 * L_pos);
+    hipStream_t st = (hipStream_t)stream;
+    Packer pk{st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, 0, 0, 0};
+    for (int l = 7; l >= 1; --l)                                  // pts_linears.l.weight[:, -256:]^T
+        pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
+    if (pk.rc) return pk.rc;
+    if (pk.w != packed_bwd + (size_t)SW_DBWD_STEPS * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: internal layout mismatch");
+    int rc = sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd_noview tail copy");
+    if (rc) return rc;
+    pk.vecs(params[16], out_ch, 256);                             // output_linear.weight rows, tile n: [h][r] = w[c][32n + frow(r,h)]
+    return pk.rc;
+}
+
 extern "C" int swnerf_pack_net_bwd(const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {
     return swnerf_pack_net_bwd_kind(SWNERF_BWD_CANON, params, L_pos, L_dir, packed_bwd, stream);
 }

@@ -139,7 +139,9 @@ static inline void pass_startup_args(PassDev& P, unsigned grid_x, int steps) {
 // tile sets and has no resampling scratch (the D-NeRF training pass runs on given depths: the coarse pass of the
 // one-model configuration is a no_grad inference pass, d_nerf/run_dnerf.py:417-421).
 template <bool DNERF, bool TRAIN> struct PassLds {
-    static constexpr int BIAS = (TRAIN && !DNERF) ? SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS : SW_LDS_BIAS_FLOATS;
+    // (TRAIN static: room for the larger of the canonical tile set, 97, and the no-view-direction set, 64 + 8 x 5 + 1 = 105)
+    static constexpr int TRAIN_TILES = SW_NOVIEW_BIAS_TILES(SW_NOVIEW_MAX_OUT) > SW_CANON_BIAS_TILES ? SW_NOVIEW_BIAS_TILES(SW_NOVIEW_MAX_OUT) : SW_CANON_BIAS_TILES;
+    static constexpr int BIAS = (TRAIN && !DNERF) ? TRAIN_TILES * SW_BIAS_TILE_FLOATS : SW_LDS_BIAS_FLOATS;
     static constexpr int FIXED = BIAS + 4 * SW_LDS_RING_FLOATS;
 };
 // PREC != 0 (bf16x3 / bf16 pass, mlp_core_x3.h): bias tiles | the workgroup's shared weight ring | per wave: gamma(d)
@@ -158,7 +160,7 @@ template <bool DNERF> struct X3Lds {
 template <bool DNERF, bool TRAIN = false, int PREC = 0, bool VIEWS = true>
 __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     static_assert(PREC == 0 || !TRAIN, "the bf16 paths cover the inference passes");
-    static_assert(VIEWS || (!DNERF && !TRAIN && PREC == 0), "the no-view-direction variant is the static fp32 inference pass");
+    static_assert(VIEWS || (!DNERF && PREC == 0), "the no-view-direction variant is a static fp32 pass (inference or TRAIN)");
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     SW_STAMP(probe_start);
     const swnerf_pass_args& a = P.a;
@@ -334,6 +336,20 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                 float* o = a.dx + (ray * S + s) * 3;
                 o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;                          // model.py:144-145
             }
+        } else if (TRAIN && !VIEWS) {
+            // the net without view directions under autograd: the trunk's side stores as below (gamma(x) with layer 0, h_l and
+            // its mask with layer l+1), h7 stored on the spot (no segment follows it), then output_linear as VALU heads
+            const int64_t prow = (ray * ntiles + tile) * 32 + j;
+            float* act_row = P.act + prow * SW_ACT_LD + 4 * h;
+            float* mask_tile = P.bits + (ray * ntiles + tile) * SW_MASK_TILE_FLOATS + lane * 4;
+            float* xs_row = P.xs + prow * SW_XS_LD + 4 * h;
+            f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+            trunk_pass<false, true, true, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, true, &mb, xs_row);
+            float o5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            head_valu_rt<8>(in, ws, a.out_ch, o5);
+            rgb[0] = o5[0] + ws.bias[0]; rgb[1] = o5[1] + ws.bias[1]; rgb[2] = o5[2] + ws.bias[2];
+            head[0] = o5[3] + ws.bias[3]; head[1] = 0.f; head[2] = 0.f;
+            extra = o5[4] + ws.bias[4];
         } else if (TRAIN) {
             // the same tile, and everything the backward needs goes out as side stores of the segments (mlp_core.h
             // SideStore): gamma(x) with layer 0, h_l and its ReLU mask with layer l+1, feature with the view layer

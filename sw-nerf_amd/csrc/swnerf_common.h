@@ -90,6 +90,11 @@
 #define SW_DBWD_BIAS_TILES 24
 #define SW_DBWD_FLOATS (SW_DBWD_W_FLOATS + SW_DBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
+// net without view directions (SWNERF_NET_NOVIEW): L7^T .. L1^T like the deformation net's chain, then output_linear.weight
+// [out_ch <= 5, 256] as out_ch x 8 bias-style tiles (d h7 = sum_c w_c . d raw_c on the VALU)
+#define SW_NVBWD_BIAS_TILES (8 * SW_NOVIEW_MAX_OUT)
+#define SW_NVBWD_FLOATS (SW_DBWD_W_FLOATS + SW_NVBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+
 // ---- bf16x3 path (mlp_core_x3.h): canonical net as k-block-major groups of [A_hi 1 KiB][A_lo 1 KiB], 8 groups per chunk --
 // groups: L0 8x4 | L1..L4 8x16 each | L5 8x20 (h then gamma(x)) | L6 L7 8x16 | FEAT 8x16 | VIEWS 4x18 (feature then gamma(d))
 #define SW_X3_CANON_GROUPS (32 + 4 * 128 + 160 + 2 * 128 + 128 + 72)

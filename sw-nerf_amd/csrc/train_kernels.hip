@@ -231,16 +231,22 @@ struct PassBwdDev {
     // the position-encoding band count, and the outputs grad_d [rows, SW_ACT_LD], g_dx [rows, 4] (= d dx, 4th column 0)
     const float* bits_d; const float* dx; const float* g_pd; int Lp;
     float* grad_d; float* g_dx;
+    // net without view directions (MODE 2): channels of output_linear (4 or 5); raw / g_raw are [N,S,out_ch], d_raw is [rows, 8]
+    int out_ch;
 };
 
-template <bool DNERF>
+// MODE: 0 static net with view directions | 1 DirectTemporalNeRF | 2 static net WITHOUT view directions (the stream is
+// pts_linears.7..1 transposed; output_linear.weight rides as out_ch x 8 bias-style tiles: d h7 = sum_c w_c . d raw_c on the VALU)
+template <int MODE>
 __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev P) {
+    constexpr bool DNERF = MODE == 1, NOVIEW = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
-    constexpr int BIASF = (DNERF ? SW_BWD_BIAS_TILES + SW_DBWD_BIAS_TILES : SW_BWD_BIAS_TILES) * SW_BIAS_TILE_FLOATS;
+    constexpr int BIASF = (NOVIEW ? SW_NVBWD_BIAS_TILES : (DNERF ? SW_BWD_BIAS_TILES + SW_DBWD_BIAS_TILES : SW_BWD_BIAS_TILES)) * SW_BIAS_TILE_FLOATS;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-    bias_to_lds(lds_all, P.b0, BIASF);
+    const int oc = NOVIEW ? P.out_ch : 4;
+    bias_to_lds(lds_all, P.b0, NOVIEW ? oc * 8 * SW_BIAS_TILE_FLOATS : BIASF);
     if (ray >= P.n_rays) return;
     float* lds_ring = lds_all + BIASF + wv * SW_LDS_RING_FLOATS;
     float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
@@ -253,7 +259,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
     const float rox = rb[0], roy = rb[1], roz = rb[2], ddx = rb[3], ddy = rb[4], ddz = rb[5];
     const float dnorm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     const float* zv = P.z + ray * S;
-    const float* raw = P.raw + ray * S * 4;
+    const float* raw = P.raw + ray * S * oc;
     WStream ws;
     ws_start(ws, P.w0, lds_all, lds_ring, lane);      // the weight ring fills while the compositing backward runs
 
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         const float z = zv[sc];
         float dist = (s + 1 < S) ? (zv[s + 1] - z) : 1e10f;
         dist *= dnorm;
-        float sg = raw[sc * 4 + 3];
+        float sg = raw[sc * oc + 3];
         if (P.noise) sg += P.noise[ray * S + sc];
         float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
         if (!live) alpha = 0.f;
@@ -298,7 +304,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         const int s = ch * 64 + lane;
         const bool live = s < S;
         const int sc = live ? s : S - 1;
-        const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + sc * 4);
+        f32x4 r4;
+        if (NOVIEW) { r4[0] = raw[sc * oc]; r4[1] = raw[sc * oc + 1]; r4[2] = raw[sc * oc + 2]; r4[3] = raw[sc * oc + 3]; }   // rows of 5 floats are not 16-byte aligned
+        else r4 = *reinterpret_cast<const f32x4*>(raw + sc * 4);
         const float z = zv[sc];
         const float c0 = 1.f / (1.f + expf(-r4[0])), c1 = 1.f / (1.f + expf(-r4[1])), c2 = 1.f / (1.f + expf(-r4[2]));
         const float w = live ? W_[sc] : 0.f, T = live ? T_[sc] : 0.f;
@@ -335,12 +343,57 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         const int64_t tix = ray * ntiles + tile;
         const int64_t prow = tix * 32 + j;
         f32x4 dr = *reinterpret_cast<const f32x4*>(dR + 4 * sc);
-        if (P.g_raw) dr += *reinterpret_cast<const f32x4*>(P.g_raw + (ray * S + sc) * 4);
-        if (!live) dr = nomask;
-        if (h == 0) *reinterpret_cast<f32x4*>(P.d_raw + prow * 4) = dr;
+        float dr5 = 0.f;                                                     // NOVIEW, out_ch 5: the fifth channel gets a gradient from g_raw alone
+        if (P.g_raw) {
+            if (NOVIEW) {
+                const float* gq = P.g_raw + (ray * S + sc) * oc;
+                dr[0] += gq[0]; dr[1] += gq[1]; dr[2] += gq[2]; dr[3] += gq[3];
+                if (oc == 5) dr5 = gq[4];
+            } else {
+                dr += *reinterpret_cast<const f32x4*>(P.g_raw + (ray * S + sc) * 4);
+            }
+        }
+        if (!live) { dr = nomask; dr5 = 0.f; }
+        if (h == 0) {
+            if (NOVIEW) {                                                    // [rows, 8]: the A operand of output_linear's weight-gradient GEMM
+                const f32x4 hi4 = {dr5, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(P.d_raw + prow * 8) = dr;
+                *reinterpret_cast<f32x4*>(P.d_raw + prow * 8 + 4) = hi4;
+            } else {
+                *reinterpret_cast<f32x4*>(P.d_raw + prow * 4) = dr;
+            }
+        }
         float* grad_row = P.grad + prow * SW_ACT_LD + 4 * h;
         MaskRing mr;
         mask_start(mr, P.bits, tix, lds_emb + 2 * 16 * 64, lane);
+        f32x16 in[8], out[8];
+        if constexpr (NOVIEW) {
+            mask_fetch(mr, 7);
+            // d h7 = output_linear.weight^T . d raw: out_ch weight rows as bias-style tiles (tile n of channel c: [h][r])
+            const float* wt = lds_all + h * 16;
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + (0 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + (1 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                    const f32x4 w2 = *reinterpret_cast<const f32x4*>(wt + (2 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+                    const f32x4 w3 = *reinterpret_cast<const f32x4*>(wt + (3 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[n][4 * g + e] = w0[e] * dr[0] + w1[e] * dr[1] + w2[e] * dr[2] + w3[e] * dr[3];
+                }
+            if (oc == 5) {                                                   // wave-uniform
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + (4 * 8 + n) * SW_BIAS_TILE_FLOATS + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out[n][4 * g + e] += w4[e] * dr5;
+                    }
+            }
+            ws_wait<0>();            // h7's mask has landed (no segment lies between its fetch and its use here: once per tile, ~1 us)
+        } else {
         mask_fetch(mr, 8);
         f32x16 k1[1];
 #pragma unroll
@@ -350,9 +403,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
         mask_apply<4>(mask_take(mr), dhv);
         mask_fetch(mr, 7);
-        f32x16 in[8], out[8];
         seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
         seg_mfma<8, 8, SEG_BIAS_SCALED, 8>(out, in, ws, dr[3], SideStore{grad_row + SW_ACT_FEAT, nullptr, nomask});
+        }
 #pragma nounroll
         for (int l = 7; l >= 1; --l) {
 #pragma unroll
@@ -510,8 +563,9 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     const swnerf_pass_args& a = *args;
     if (a.n_rays == 0 && a.packed) return 0;
     if (!a.packed || !a.ray_batch || !act || !bits || !xs) return sw_fail(SWNERF_E_ARG, "render_pass_train: NULL pointer");
-    if (a.kind != SWNERF_NET_CANON || (a.cols != 11 && a.cols != 12))
-        return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: the static net (SWNERF_NET_CANON) with an 11- or 12-column ray batch");
+    const bool noview = a.kind == SWNERF_NET_NOVIEW;
+    if (noview ? a.cols != 8 : (a.kind != SWNERF_NET_CANON || (a.cols != 11 && a.cols != 12)))
+        return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: the static net (SWNERF_NET_CANON, 11- or 12-column ray batch) or the one without view directions (SWNERF_NET_NOVIEW, 8 columns)");
     if (a.n_rays < 0 || a.n_samples < 2 || a.n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: 2 <= n_samples <= %d (got %d)", PB_SMAX, a.n_samples);
     if (!a.raw || !(a.z_vals || a.z_out)) return sw_fail(SWNERF_E_ARG, "render_pass_train: the backward needs raw and the depths (z_vals given or z_out)");
     if (a.L_pos < 0 || a.L_pos > 10 || a.L_dir < 0 || a.L_dir > 4) return sw_fail(SWNERF_E_UNSUPP, "render_pass_train: embedder bands (%d,%d) exceed (10,4)", a.L_pos, a.L_dir);
@@ -519,7 +573,8 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     if (a.dx) return sw_fail(SWNERF_E_ARG, "render_pass_train: no dx output (static net)");
     PassDev P;
     P.a = a;
-    int rc = stream_ptrs(a.kind, a.packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
+    int rc = noview ? stream_ptrs_noview(a.packed, a.out_ch, &P.w0, &P.b0, &P.nbias, &P.two_pass)
+                    : stream_ptrs(a.kind, a.packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = nullptr; P.bits_d = nullptr; P.xs_d = nullptr;
     P.sort_n = 0; P.sort_s = 0;
@@ -538,8 +593,9 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
         lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
     }
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
-    pass_startup_args(P, grid.x, SW_CANON_STEPS);
-    hipLaunchKernelGGL((render_pass_kernel<false, true>), grid, block, lds, (hipStream_t)stream, P);
+    pass_startup_args(P, grid.x, noview ? SW_NOVIEW_STEPS : SW_CANON_STEPS);
+    if (noview) hipLaunchKernelGGL((render_pass_kernel<false, true, 0, false>), grid, block, lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((render_pass_kernel<false, true>), grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_train launch");
 }
 
@@ -559,8 +615,32 @@ extern "C" int swnerf_render_pass_backward(const float* packed_bwd, const float*
     const size_t lds = (SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
     P.bits_d = nullptr; P.dx = nullptr; P.g_pd = nullptr; P.Lp = 0; P.grad_d = nullptr; P.g_dx = nullptr;
-    hipLaunchKernelGGL(render_pass_backward_kernel<false>, grid, block, lds, (hipStream_t)stream, P);
+    P.out_ch = 4;
+    hipLaunchKernelGGL(render_pass_backward_kernel<0>, grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_backward launch");
+}
+
+// ... and for the net without view directions (SWNERF_NET_NOVIEW): raw / g_raw [N,S,out_ch], d_raw [rows, 8] (columns
+// >= out_ch zero: the 16-byte aligned A operand of output_linear's weight-gradient GEMM), packed_bwd = swnerf_pack_net_bwd_noview
+extern "C" int swnerf_render_pass_backward_noview(const float* packed_bwd, const float* bits, const float* raw, const float* z_vals,
+                                                  const float* ray_batch, int cols, const float* noise, int64_t n_rays, int n_samples,
+                                                  int white_bkgd, int out_ch, const float* g_rgb, const float* g_disp, const float* g_acc,
+                                                  const float* g_raw, float* grad, float* d_raw8, void* stream) {
+    if (n_rays == 0 && packed_bwd) return 0;
+    if (!packed_bwd || !bits || !raw || !z_vals || !ray_batch || !grad || !d_raw8 || n_rays < 0)
+        return sw_fail(SWNERF_E_ARG, "render_pass_backward_noview: NULL pointer or negative n_rays");
+    if (n_samples < 2 || n_samples > PB_SMAX) return sw_fail(SWNERF_E_UNSUPP, "render_pass_backward_noview: 2 <= n_samples <= %d (got %d)", PB_SMAX, n_samples);
+    if (cols < 8 || out_ch < 4 || out_ch > SW_NOVIEW_MAX_OUT) return sw_fail(SWNERF_E_ARG, "render_pass_backward_noview: cols %d / out_ch %d", cols, out_ch);
+    PassBwdDev P;
+    P.w0 = packed_bwd; P.b0 = packed_bwd + SW_DBWD_W_FLOATS; P.bits = bits; P.raw = raw; P.z = z_vals; P.ray_batch = ray_batch;
+    P.cols = cols; P.noise = noise; P.n_rays = n_rays; P.S = n_samples; P.white = white_bkgd;
+    P.g_rgb = g_rgb; P.g_disp = g_disp; P.g_acc = g_acc; P.g_raw = g_raw; P.grad = grad; P.d_raw = d_raw8;
+    P.bits_d = nullptr; P.dx = nullptr; P.g_pd = nullptr; P.Lp = 0; P.grad_d = nullptr; P.g_dx = nullptr;
+    P.out_ch = out_ch;
+    const size_t lds = (SW_NVBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
+    const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+    hipLaunchKernelGGL(render_pass_backward_kernel<2>, grid, block, lds, (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "render_pass_backward_noview launch");
 }
 
 // ---- the same for DirectTemporalNeRF at t != 0 (model.py:128-151; loss of d_nerf/run_dnerf.py:690-725) ----------------
@@ -609,6 +689,7 @@ extern "C" int swnerf_render_pass_backward_dnerf(const float* packed_bwd_fused, 
     P.bits_d = bits_d; P.dx = dx; P.g_pd = g_position_delta; P.Lp = L_pos; P.grad_d = grad_d; P.g_dx = g_dx;
     const size_t lds = ((SW_BWD_BIAS_TILES + SW_DBWD_BIAS_TILES) * SW_BIAS_TILE_FLOATS + 4 * SW_LDS_RING_FLOATS + 4 * PB_WAVE_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
-    hipLaunchKernelGGL(render_pass_backward_kernel<true>, grid, block, lds, (hipStream_t)stream, P);
+    P.out_ch = 4;
+    hipLaunchKernelGGL(render_pass_backward_kernel<1>, grid, block, lds, (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "render_pass_backward_dnerf launch");
 }

@@ -19,6 +19,7 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
            "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
            "swnerf_render_pass_train_dnerf", "swnerf_render_pass_backward_dnerf", "swnerf_unslot_grad_time",
+           "swnerf_packed_bwd_noview_floats", "swnerf_pack_net_bwd_noview", "swnerf_render_pass_backward_noview",
            "swnerf_linear", "swnerf_gemm_nn", "swnerf_relu_mask",
            "swnerf_packed_x3_floats", "swnerf_pack_net_x3", "swnerf_render_pass_x3",
            "swnerf_packed_x3_floats_kind", "swnerf_pack_net_x3_kind"]
@@ -105,6 +106,11 @@ def lib():
     L.swnerf_render_pass_train.argtypes = [POINTER(PassArgs), c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_render_pass_backward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.swnerf_packed_bwd_noview_floats.restype = c_size_t
+    L.swnerf_packed_bwd_noview_floats.argtypes = []
+    L.swnerf_pack_net_bwd_noview.argtypes = [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]
+    L.swnerf_render_pass_backward_noview.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int,
+                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_render_pass_train_dnerf.argtypes = [POINTER(PassArgs)] + [c_void_p] * 7
     L.swnerf_render_pass_backward_dnerf.argtypes = [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int64, c_int, c_int, c_int] + [c_void_p] * 9
     L.swnerf_unslot_grad_time.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
@@ -121,10 +127,10 @@ def lib():
     L.swnerf_pack_net_x3_kind.argtypes = [c_int, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
-                        "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows"):
+                        "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows", "swnerf_packed_bwd_noview_floats"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 104:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 104 - rebuild it "
+    if L.swnerf_version() != 105:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 105 - rebuild it "
                            "(python __graft_entry__.py)")
     _lib = L
     return L

@@ -191,6 +191,34 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slo
     _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
 
 
+def _noview_slot_buffers(device):
+    """Zeroed accumulators of the fused NOVIEW training pass: slot-ordered gamma(x) columns of pts_linears.0 / .5 and the
+    8-row form of output_linear's gradient (A = d raw [rows, 8]) with its bias."""
+    z = torch.zeros(256 * 64 + 256 * 64 + 8 * 256 + 8, dtype=torch.float32, device=device)
+    return z[:16384].view(256, 64), z[16384:32768].view(256, 64), z[32768:34816].view(8, 256), z[34816:34824]
+
+
+def _noview_weight_grads_slots(L, st, M, grad, act, xs, d_raw8, Cpos, g, bufs):
+    """dW / db of the 8x256 net without view directions (g: zeroed tensors in _NOVIEW_ORDER), accumulating per row chunk:
+    model.py:39-47,59-60 reversed.  grad / act columns 0..2047 = pts_linears.0..7; xs slots 0..63 = gamma(x)."""
+    c0s, c5s, w8, b8 = bufs
+    mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
+    mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
+    for l in (1, 2, 3, 4, 6, 7):
+        mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, g[2 * l], 0, g[2 * l + 1])
+    _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
+    mm(d_raw8, 0, 8, act, 1792, 256, w8, 0, b8)                                # output_linear (rows 0..out_ch-1)
+
+
+def _noview_unslot(L, st, bufs, Lp, g):
+    c0s, c5s, w8, b8 = bufs
+    for cs, W in ((c0s, g[0]), (c5s, g[10])):
+        _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), 64, 256, 0, 64, Lp, 0, W.data_ptr(), W.stride(0), 0, st), "unslot_grad")
+    oc = g[16].shape[0]
+    g[16] = g[16] + w8[:oc]
+    g[17] = g[17] + b8[:oc]
+
+
 def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g):
     c0s, c5s, cvs = slot_bufs
     for cs, nslots, slot0, W, col0 in ((c0s, 64, 0, g[0], 0), (c5s, 64, 0, g[10], 0), (cvs, 32, 64, g[16], 256)):
@@ -438,6 +466,21 @@ class _PackedMixin:
             _lib.check(L.swnerf_pack_net_noview(arr, Lp, out_ch, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_noview")
             self._packed, self._pack_key = buf, key
         return self._packed, Lp, out_ch
+
+    def packed_bwd_noview(self):
+        """The transposed stream of the NOVIEW net's dX chain (swnerf_pack_net_bwd_noview), cached like packed_bwd()."""
+        names, Lp, out_ch = self._noview_params()
+        sd = dict(self.named_parameters())
+        ps = [sd[n] for n in names]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._pack_bwd.get("noview", (None, None))[0] != key:
+            L = _lib.lib()
+            ps32 = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous() for p in ps]
+            arr = (ctypes.c_void_p * len(ps32))(*[p.data_ptr() for p in ps32])
+            buf = torch.empty(L.swnerf_packed_bwd_noview_floats(), dtype=torch.float32, device=ps[0].device)
+            _lib.check(L.swnerf_pack_net_bwd_noview(arr, Lp, out_ch, _lib.ptr(buf), _lib.stream_of(buf)), "pack_net_bwd_noview")
+            self._pack_bwd["noview"] = (key, buf)
+        return self._pack_bwd["noview"][1]
 
     def packed(self):
         """(kind, packed float tensor, L_pos, L_dir, L_time)"""

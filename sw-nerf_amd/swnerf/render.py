@@ -99,8 +99,8 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
     real = [net for net in nets if net is not None]
     if nets_without_views(nets):
         # use_viewdirs=False (the reference's argparse default): no direction encoder exists (nerf/run.py:227-229 leaves
-        # embeddirs_fn None), rays have 8 columns; the fused pass has a variant without the view branch.  Inference only.
-        if need_time or wants_grad(nets) or any(net.input_ch != ef.out_dim for net in real):
+        # embeddirs_fn None), rays have 8 columns; the fused pass has a variant without the view branch (and its backward).
+        if need_time or any(net.input_ch != ef.out_dim for net in real):
             return None
         return ef.multires, 0, 0
     if not (isinstance(edf, EmbedFn) and edf.input_dims == 3):
@@ -224,16 +224,23 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, rb, z_vals, S, lindisp, t_rand, noise, white_bkgd, n_importance, u, *params):
-        kind, packed, Lp, Ld, _ = net.packed()
+        noview = net._noview_params() is not None              # use_viewdirs=False: 8-column rays, raw [N,S,out_ch]
+        out_ch = 4
+        if noview:
+            packed, Lp, out_ch = net.packed_noview()
+            kind, Ld = _lib.NET_NOVIEW, 0
+        else:
+            kind, packed, Lp, Ld, _ = net.packed()
         L = _lib.lib()
         N, cols = rb.shape
         dev = rb.device
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         rows = L.swnerf_train_rows(N, S)
         act, bits, xs = new(rows, L.swnerf_act_floats_per_row()), new(L.swnerf_mask_floats(rows)), new(rows, L.swnerf_xs_floats_per_row())
-        raw, rgb, disp, acc = new(N, S, 4), new(N, 3), new(N), new(N)
+        raw, rgb, disp, acc = new(N, S, out_ch), new(N, 3), new(N), new(N)
         a = _lib.PassArgs()
         a.ray_batch, a.n_rays, a.cols, a.kind, a.packed = rb.data_ptr(), N, cols, kind, packed.data_ptr()
+        a.out_ch = out_ch
         a.run_deform, a.L_pos, a.L_dir, a.L_time, a.n_samples = 0, Lp, Ld, 0, S
         a.lindisp, a.white_bkgd = int(bool(lindisp)), int(bool(white_bkgd))
         a.rgb_map, a.disp_map, a.acc_map, a.raw = rgb.data_ptr(), disp.data_ptr(), acc.data_ptr(), raw.data_ptr()
@@ -258,7 +265,7 @@ class _FusedPassTrain(torch.autograd.Function):
         if PASS_HOOK is not None:
             PASS_HOOK("end", N, S)
         ctx.net, ctx.S, ctx.white, ctx.bands = net, S, bool(white_bkgd), (Lp, Ld)
-        ctx.has_noise = noise is not None
+        ctx.has_noise, ctx.noview, ctx.out_ch = noise is not None, noview, out_ch
         ctx.save_for_backward(rb, z, raw, act, bits, xs, noise if noise is not None else new(0), *params)
         ctx.mark_non_differentiable(z_fine, z_std)
         # raw is an output as well (retraw=True is what the reference's train() passes, nerf/run.py:685): a gradient
@@ -267,7 +274,8 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
-        from .model import _zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan
+        from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan,
+                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot)
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -277,40 +285,52 @@ class _FusedPassTrain(torch.autograd.Function):
         c = lambda g: None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_acc, g_raw = c(g_rgb), c(g_disp), c(g_acc), c(g_raw)
         g = _zero_grads(params)
-        slot_bufs, rgb4 = _slot_buffers(rb.device), _rgb4_buffers(rb.device)
+        nv = ctx.noview
+        if nv:
+            slot_bufs, rgb4 = _noview_slot_buffers(rb.device), None
+        else:
+            slot_bufs, rgb4 = _slot_buffers(rb.device), _rgb4_buffers(rb.device)
         # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
         # it run per CHUNK of rays, so only one chunk of it is ever alive (GEMMs accumulate: C += A^T.B).  A chunk is
         # 393 216 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
         rows_per_ray = act.shape[0] // N
         chunk = max(4, (TRAIN_BWD_CHUNK_ROWS // rows_per_ray) // 4 * 4)
-        packed_bwd = net.packed_bwd()
+        packed_bwd = net.packed_bwd_noview() if nv else net.packed_bwd()
         mask_per_ray = bits.numel() // N
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
         grad = torch.empty((min(N, chunk) * rows_per_ray, act.shape[1]), dtype=torch.float32, device=rb.device)
-        d_raw = torch.empty((min(N, chunk) * rows_per_ray, 4), dtype=torch.float32, device=rb.device)
+        d_raw = torch.empty((min(N, chunk) * rows_per_ray, 8 if nv else 4), dtype=torch.float32, device=rb.device)
         fan = _Fan(rb.device)                                    # the GEMMs of a chunk fan out over side streams (model._Fan)
         for r0 in range(0, N, chunk):
             r1 = min(N, r0 + chunk)
             n, m = r1 - r0, (r1 - r0) * rows_per_ray
-            _lib.check(L.swnerf_render_pass_backward(
-                _lib.ptr(packed_bwd), _lib.ptr(bits[r0 * mask_per_ray:r1 * mask_per_ray]), _lib.ptr(raw[r0:r1]), _lib.ptr(z[r0:r1]),
-                _lib.ptr(rb[r0:r1]), cols, _lib.ptr(noise[r0:r1]) if ctx.has_noise else None, n, S, int(ctx.white),
-                _lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)),
-                _lib.ptr(grad), _lib.ptr(d_raw), st),
-                "render_pass_backward")
+            common = (_lib.ptr(packed_bwd), _lib.ptr(bits[r0 * mask_per_ray:r1 * mask_per_ray]), _lib.ptr(raw[r0:r1]), _lib.ptr(z[r0:r1]),
+                      _lib.ptr(rb[r0:r1]), cols, _lib.ptr(noise[r0:r1]) if ctx.has_noise else None, n, S, int(ctx.white))
+            grads_in = (_lib.ptr(sl(g_rgb, r0, r1)), _lib.ptr(sl(g_disp, r0, r1)), _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)),
+                        _lib.ptr(grad), _lib.ptr(d_raw), st)
+            if nv:
+                _lib.check(L.swnerf_render_pass_backward_noview(*common, ctx.out_ch, *grads_in), "render_pass_backward_noview")
+            else:
+                _lib.check(L.swnerf_render_pass_backward(*common, *grads_in), "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
             fan.fork()
-            _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
+            if nv:
+                _noview_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, g, slot_bufs)
+            else:
+                _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
             fan.join()                                           # before the next chunk's backward kernel overwrites grad / d_raw
-        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
-        _rgb4_finish(g, rgb4)
+        if nv:
+            _noview_unslot(L, st, slot_bufs, Lp, g)
+        else:
+            _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
+            _rgb4_finish(g, rgb4)
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
 def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,
                       n_importance=0, u=None):
     """One differentiable fused pass (`_FusedPassTrain`): dict with rgb_map disp_map acc_map raw (+ z_fine z_std)."""
-    from .model import _CANON_ORDER
+    from .model import _CANON_ORDER, _NOVIEW_ORDER
     rb = _lib.dev_f32(ray_batch.detach(), "ray_batch")
     N, S = rb.shape[0], int(n_samples)
     chk = lambda t, name, last: None if t is None else _lib.dev_f32(t.detach(), name, last)
@@ -320,7 +340,8 @@ def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, 
             raise ValueError(f"swnerf.render_pass_train: {name} must have {N} rows, got {tuple(t.shape)}")
     sd = dict(net.named_parameters())
     rgb, disp, acc, z_fine, z_std, raw = _FusedPassTrain.apply(net, rb, z_vals, S, bool(lindisp), t_rand, noise, bool(white_bkgd),
-                                                               int(n_importance), u, *[sd[n] for n in _CANON_ORDER])
+                                                               int(n_importance), u,
+                                                               *[sd[n] for n in (_NOVIEW_ORDER if net._noview_params() is not None else _CANON_ORDER)])
     out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "raw": raw}
     if n_importance > 0:
         out["z_fine"], out["z_std"] = z_fine, z_std

@@ -269,3 +269,111 @@ def test_generic_training_matches_autograd(dev):
             rg = sd[k].grad
             # the gradient through gamma(x+dx) carries the 2^9 band: conditioning, not arithmetic
             assert float((p.grad.cpu() - rg).abs().max()) <= 2e-3 * max(float(rg.abs().max()), 1e-12), f"dnerf {k}"
+
+
+def test_fused_training_without_viewdirs(dev, monkeypatch):
+    """loss.backward() of a use_viewdirs=False run (the reference's argparse default; train() nerf/run.py:684-708) on the
+    fused pass: swnerf_render_pass_train with SWNERF_NET_NOVIEW + swnerf_render_pass_backward_noview (compositing backward,
+    output_linear^T on the VALU, pts_linears.7..1^T on the MFMA ring) + the weight-gradient GEMMs.  Every parameter gradient
+    against the float64 evaluation of the oracle, ReLU flips of near-zero units accounted for exactly (tests/flipcheck.py):
+    2e-5 of each tensor's max.
+    (a) coarse-only passes: 5- and 4-channel heads, ragged sizes (S not a multiple of 32, N not a multiple of 4, S = 2 and
+        S = 256), a gradient on every channel of the returned raw (retraw=True) and on disp / acc, raw noise, several backward
+        chunks; (b) the layer-by-layer generic path it replaces (SWNERF_TRAIN_OP_PATH=1) through the same check;
+    (c) the hierarchical 64+128 step with two nets: the coarse net's gradient equals that of the coarse-only step (the fine
+        depths are detached, nerf/run.py:398), the fine net's is checked on the depths the step used; then 20 Adam steps."""
+    import swnerf.embedder as embedder, swnerf.render as render, swnerf.model as model
+    from flipcheck import noview_flip_aware_check
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=None, netchunk=1024 * 64)
+    sds = cases.g12_weights()
+
+    def mk(i, oc=5):
+        sd = dict(sds[i])
+        sd["output_linear.weight"], sd["output_linear.bias"] = sd["output_linear.weight"][:oc], sd["output_linear.bias"][:oc]
+        m = model.vallina_NeRF(**dict(cases.G12_NET, output_ch=oc))
+        m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+        return m.to(dev).train(), sd
+
+    used = lambda net: {k: p.grad for k, p in net.named_parameters() if k.startswith(("pts_linears", "output_linear"))}
+    rng = np.random.default_rng(21)
+    with torch.enable_grad():
+        for n, S, oc, white, chunk_rows, noise_std in ((64, 64, 5, True, 393216, 0.), (37, 40, 5, False, 1024, 1.), (5, 33, 4, True, 64, 0.),
+                                                       (3, 2, 5, False, 393216, 0.), (2, 256, 4, True, 393216, 0.5)):
+            monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", chunk_rows)
+            g = cases.g7_inputs(n=n, seed=300 + n)
+            rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.)[:, :8].contiguous()
+            tgt = T(rng.uniform(0, 1, (n, 3)).astype(np.float32))
+            wa, wd = T(rng.standard_normal(n).astype(np.float32)), T(rng.standard_normal(n).astype(np.float32))
+            Graw = T((1e-3 * rng.standard_normal((n, S, oc))).astype(np.float32))
+
+            def ray_loss(ret, idx):                        # a sum over rays: the reference's img2mse + terms on disp, acc and raw
+                c = lambda t: t[idx.to(t.device)].to(ret["raw"])
+                ok = ~torch.isnan(ret["disp_map"])
+                return (((ret["rgb_map"] - c(tgt)) ** 2).sum() / (3 * n) + 0.1 * (ret["acc_map"] * c(wa)).sum() / n
+                        + 0.01 * (torch.where(ok, ret["disp_map"], torch.zeros_like(ret["disp_map"])) * c(wd)).sum() / n + (ret["raw"] * c(Graw)).sum())
+
+            kw = dict(retraw=True, N_importance=0, white_bkgd=white, raw_noise_std=noise_std, pytest=True)
+            np.random.seed(0)
+            noise = T((np.random.rand(n, S) * noise_std).astype(np.float32)) if noise_std > 0 else None     # what pytest=True draws (ray.py:176-184)
+            net, sd_np = mk(0, oc)
+            assert render.fused_plan(q, [net, None], allow_train=True) == (10, 0, 0)
+            hits = []
+            monkeypatch.setattr(render, "PASS_HOOK", lambda *a: hits.append(a))
+            ret = render.render_rays(rb.to(dev), net, q, S, **kw)
+            monkeypatch.setattr(render, "PASS_HOOK", None)
+            assert hits and ret["raw"].shape == (n, S, oc) and ret["raw"].requires_grad      # the fused training pass ran
+            ray_loss(ret, torch.arange(n)).backward()
+            if noise is None:
+                o = O.render_rays_generic(rb, lambda e: O.generic_mlp(O.to_torch_sd(sd_np), e, 8, [4], 63, 0, False), S, 0, white_bkgd=white, retraw=True)
+                for k in ("rgb_map", "acc_map"):
+                    close(ret[k], o[k], atol=2e-5, what=f"training forward {k} (n={n} S={S})")
+                close(ret["raw"], o["raw"], atol=1e-3, rtol=1e-4, what="training forward raw")
+            z = O.coarse_z(rb[:, 6:7], rb[:, 7:8], S)
+            what = f"fused NOVIEW training vs float64 autograd (n={n} S={S} out_ch={oc})"
+            fl = noview_flip_aware_check(sd_np, rb, z, white, ray_loss, used(net), what, noise=noise)
+            # (b) the generic layer-by-layer path on the same call
+            monkeypatch.setenv("SWNERF_TRAIN_OP_PATH", "1")
+            net_g, _ = mk(0, oc)
+            ret_g = render.render_rays(rb.to(dev), net_g, q, S, **kw)
+            monkeypatch.delenv("SWNERF_TRAIN_OP_PATH")
+            ray_loss(ret_g, torch.arange(n)).backward()
+            close(ret["rgb_map"], ret_g["rgb_map"], atol=2e-5, what="fused vs generic training forward")
+            fg = noview_flip_aware_check(sd_np, rb, z, white, ray_loss, used(net_g), what.replace("fused", "generic"), noise=noise)
+            print(f"\n[parity] NOVIEW training n={n} S={S} out_ch={oc}: all gradients within 2e-5 of float64; ReLU flips (of risky units) fused {fl}, generic {fg}")
+        # (c) the hierarchical step, two nets
+        monkeypatch.setattr(render, "TRAIN_BWD_CHUNK_ROWS", 4096)
+        g = cases.g12_inputs()
+        rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), g["near"], g["far"])[:48, :8].contiguous()
+        tgt = T(rng.uniform(0, 1, (48, 3)).astype(np.float32))
+        (nc, _), (nf, sd_f) = mk(0), mk(1)
+        ret = render.render_rays(rb.to(dev), nc, q, 64, retraw=True, N_importance=128, network_fine=nf, white_bkgd=True)
+        assert list(ret.keys()) == ["rgb_map", "disp_map", "acc_map", "raw", "rgb0", "disp0", "acc0", "z_std"] and ret["raw"].shape == (48, 192, 5)
+        (torch.mean((ret["rgb_map"] - tgt.to(dev)) ** 2) + torch.mean((ret["rgb0"] - tgt.to(dev)) ** 2)).backward()
+        nc2, _ = mk(0)
+        r0 = render.render_rays(rb.to(dev), nc2, q, 64, N_importance=0, white_bkgd=True)
+        torch.mean((r0["rgb_map"] - tgt.to(dev)) ** 2).backward()
+        close(ret["rgb0"], r0["rgb_map"], atol=0, what="rgb0 of the hierarchical step = the coarse-only pass")
+        g2 = dict(nc2.named_parameters())
+        for k, p in nc.named_parameters():
+            if p.grad is not None:
+                scale = max(float(g2[k].grad.abs().max()), 1e-12)
+                assert float((p.grad - g2[k].grad).abs().max()) <= 2e-6 * scale, f"coarse net {k}"
+        with torch.no_grad():
+            z_fine = render.render_pass(rb.to(dev), nc2, 64, white_bkgd=True, want=[], n_importance=128)["z_fine"].cpu()
+        fine_loss = lambda r, idx: ((r["rgb_map"] - tgt[idx].to(r["raw"])) ** 2).sum() / (3 * 48)
+        fl = noview_flip_aware_check(sd_f, rb, z_fine, True, fine_loss, used(nf), "fine net of the hierarchical NOVIEW step on the step's depths")
+        print(f"\n[parity] NOVIEW hierarchical step, fine net (48 x 192 rows): within 2e-5 of float64; ReLU flips (of risky units) {fl}")
+        # optimizer.step() changes the weights in place: the packed streams (forward and transposed) must follow
+        opt = torch.optim.Adam(list(nc.parameters()) + list(nf.parameters()), lr=5e-4)
+        before = float(torch.mean((ret["rgb_map"].detach() - tgt.to(dev)) ** 2))
+        for _ in range(20):
+            opt.zero_grad()
+            r = render.render_rays(rb.to(dev), nc, q, 64, N_importance=128, network_fine=nf, white_bkgd=True)
+            loss = torch.mean((r["rgb_map"] - tgt.to(dev)) ** 2) + torch.mean((r["rgb0"] - tgt.to(dev)) ** 2)
+            loss.backward()
+            opt.step()
+        after = float(torch.mean((r["rgb_map"].detach() - tgt.to(dev)) ** 2))
+        print(f"\n[train] NOVIEW fused, 20 Adam steps on 48 rays: mse {before:.4f} -> {after:.4f}")
+        assert after < before

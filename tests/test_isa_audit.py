@@ -47,8 +47,8 @@ def test_mfma_kernels_isa(asm):
         steps = 64 + 256 + 64 + 256 + 144 + (96 if "kernelILb1" in name else 0)
         if "query_points" in name:
             steps = 64 + 256 + 64 + 256 + 144
-        if "render_pass_kernelILb0ELb0ELi0ELb0EE" in name or "mlp_forward_noview" in name:   # no view branch: L0 (64), trunk body (256), skip-emb (64)
-            steps = 64 + 256 + 64
+        if "render_pass_kernelILb0ELb0ELi0ELb0EE" in name or "render_pass_kernelILb0ELb1ELi0ELb0EE" in name or "mlp_forward_noview" in name:
+            steps = 64 + 256 + 64                  # no view branch (inference, TRAIN): L0 (64), trunk body (256), skip-emb (64)
         if "mlp_backward_dx" in name:              # RGB^T (16) VIEWS^T (128) FEAT^T (256) + the L7..L1 loop body (256)
             steps = 16 + 128 + 256 + 256          # <true>: + the gamma(x) columns of pts_linears.5 and .0 (64 each)
             if "kernelILb1" in name:
@@ -59,13 +59,17 @@ def test_mfma_kernels_isa(asm):
             steps = 256
         if "render_pass_backward" in name:         # the fused backward: the same chain as mlp_backward_dx<false>, per tile
             steps = 16 + 128 + 256 + 256
-            if "kernelILb1" in name:               # D-NeRF: + the gamma(x+dx) columns (2 x 64) + the deformation loop body
+            if "kernelILi1" in name:               # D-NeRF: + the gamma(x+dx) columns (2 x 64) + the deformation loop body
                 steps += 128 + 256
+            if "kernelILi2" in name:               # no view directions: the L7..L1 loop body alone (output_linear^T runs on the VALU)
+                steps = 256
         # the backward chains also fetch the ReLU bit masks by LDS-DMA: one fetch before the ring is primed, one per
         # static use site after it (mlp_backward_dx: views hidden, h7, loop body; deformation: h7, loop body)
         masks = 3 if ("mlp_backward_dx" in name or "render_pass_backward" in name) else (2 if "deform_backward_dx" in name else 0)
-        if "render_pass_backward_kernelILb1" in name:
+        if "render_pass_backward_kernelILi1" in name:
             masks = 5                                # canonical (3 sites) + deformation (h7, loop body)
+        if "render_pass_backward_kernelILi2" in name:
+            masks = 2                                # h7, loop body
         assert stats["mfma"] == 4 * steps, (name, stats)
         # ring priming: 8 steps in the render unit, 16 in the training unit (train_kernels.hip)
         training = any(k in name for k in ("mlp_backward_dx", "deform_", "mlp_forward_kernelILb0ELb1E", "render_pass_backward",
@@ -73,7 +77,7 @@ def test_mfma_kernels_isa(asm):
         # the fused pass pulls the weight stream into L2 at kernel start with one more static DMA site (render_pass.h pass_startup)
         warm = 1 if "render_pass_kernel" in name else 0
         assert dma == steps + (16 if training else 8) + masks + warm, (name, dma)
-    assert len(seen) == 16
+    assert len(seen) == 18
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)
         assert m, name
