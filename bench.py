@@ -381,6 +381,29 @@ def extra_configs(dev):
         for p in m.parameters():
             p.grad = None
     del opt
+    # the same step for a use_viewdirs=False run (the reference's argparse default): fused training pass of the nets without
+    # the view branch (swnerf_render_pass_train kind SWNERF_NET_NOVIEW + swnerf_render_pass_backward_noview)
+    nets_nv = [nv[0][0], nv[1][0]]
+    for m in nets_nv:
+        m.train()
+    opt_nv = torch.optim.Adam([p for m in nets_nv for p in m.parameters()], lr=5e-4, betas=(0.9, 0.999))
+    kwt_nv = dict(kw_nv, perturb=1.)
+
+    def train_step_nv():
+        rgb, disp, acc, extras = render.render(800, 800, K8, chunk=1024 * 32, rays=r2, **kwt_nv)
+        loss = torch.mean((rgb - target) ** 2) + torch.mean((extras['rgb0'] - target) ** 2)
+        opt_nv.zero_grad()
+        loss.backward()
+        opt_nv.step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    timeit("training step with use_viewdirs=False: 4096 rays x (64+128), two nets without the view branch, backward, Adam", train_step_nv,
+           N_RAND, 3 * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * flop_nv, 5, grad=True)
+    rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    for m in nets_nv:
+        m.eval()
+        for p in m.parameters():
+            p.grad = None
+    del opt_nv
     # D-NeRF training step (d_nerf/run_dnerf.py:686-735, the shipped one-model configuration): the coarse pass runs under
     # no_grad and only feeds the resampling, the fine pass trains deformation + canonical net; image loss.  FLOPs:
     # coarse forward (64 rows) + 3 x fine (192 rows), each row through both nets

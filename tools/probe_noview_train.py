@@ -17,9 +17,9 @@ embed_fn, _ = embedder.get_embedder(10, 3, 0)
 q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=None, netchunk=1024 * 64)
 kw = dict(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
 nets = []
-for seed, gain in ((20250321, 0.5), (20250322, 0.7)):
+for seed, ab in ((20250321, 0.5), (20250322, 0.7)):
     m = model.vallina_NeRF(**kw)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.noview_state_dict(seed, gain).items()}, strict=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.noview_state_dict(seed, alpha_bias=ab).items()}, strict=True)
     nets.append(m.to(dev).train())
 g = torch.Generator().manual_seed(3)
 o = torch.randn((N, 3), generator=g) * 0.1 + torch.tensor([0., 0., 4.])
