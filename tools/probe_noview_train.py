@@ -30,7 +30,10 @@ macs = 63 * 256 + 6 * 256 * 256 + (256 + 63) * 256 + 256 * 5
 flops = 3 * 2 * macs * N * (S + S + NI)
 print("| path | ms per step (forward + backward) | TFLOP/s | of the 157.3 TFLOP/s fp32 MFMA peak |")
 print("|---|---|---|---|")
+ONLY_FUSED = len(sys.argv) > 1 and sys.argv[1] == "fused"          # for rocprofv3: 2 warm-up + 7 timed steps of the fused path
 for name, env in (("fused (render_pass_train / render_pass_backward_noview)", None), ("generic layer by layer", "1")):
+    if ONLY_FUSED and env:
+        continue
     if env:
         os.environ["SWNERF_TRAIN_OP_PATH"] = env
     else:
@@ -43,12 +46,14 @@ for name, env in (("fused (render_pass_train / render_pass_backward_noview)", No
         r = render.render_rays(rb, nets[0], q, S, N_importance=NI, network_fine=nets[1], white_bkgd=True, retraw=True)
         (torch.mean((r["rgb_map"] - tgt) ** 2) + torch.mean((r["rgb0"] - tgt) ** 2)).backward()
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.5:
+    w = 0
+    while (w < 2) if ONLY_FUSED else (time.perf_counter() - t0 < 0.5):
         step()
+        w += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     k = 0
-    while k < 5 or time.perf_counter() - t0 < 1.0:
+    while (k < 7) if ONLY_FUSED else (k < 5 or time.perf_counter() - t0 < 1.0):
         step()
         k += 1
     torch.cuda.synchronize()
