@@ -19,30 +19,43 @@ from oracle import nerf_oracle as O
 
 
 def _mlp64(sd, e, flips=None, pres=None):
-    """model.py:39-47,59-60 (use_viewdirs=False) in float64 with the ReLU written as a mask; flips: {layer: bool [rows,256]}"""
-    h = e
-    for i in range(8):
-        pre = h @ sd[f"pts_linears.{i}.weight"].T + sd[f"pts_linears.{i}.bias"]
+    """vallina_NeRF.forward (model.py:39-62) in float64 with the ReLU written as a mask; flips: {layer: bool [rows, units]}
+    (layers 0..7 = pts_linears, 8 = views_linears.0).  use_viewdirs=False (model.py:59-60) when sd has output_linear and e is
+    63 wide; else e = [gamma(x) 63 | gamma(d) 27]."""
+    lin = lambda name, x: x @ sd[name + ".weight"].T + sd[name + ".bias"]
+
+    def relu(i, pre):
         if pres is not None:
             pres.append(pre.detach())
         m = pre.detach() > 0
         if flips is not None and i in flips:
             m = m ^ flips[i]
-        h = pre * m
+        return pre * m
+    pts = e[:, :63]
+    h = pts
+    for i in range(8):
+        h = relu(i, lin(f"pts_linears.{i}", h))
         if i == 4:
-            h = torch.cat([e, h], -1)
-    return h @ sd["output_linear.weight"].T + sd["output_linear.bias"]
+            h = torch.cat([pts, h], -1)
+    if e.shape[1] == 63:
+        return lin("output_linear", h)
+    sigma = lin("alpha_linear", h)
+    hv = relu(8, lin("views_linears.0", torch.cat([lin("feature_linear", h), e[:, 63:]], -1)))
+    return torch.cat([lin("rgb_linear", hv), sigma], -1)
 
 
-def noview_flip_aware_check(sd_np, rb, z, white_bkgd, ray_loss, gpu_grads, what, thr=5e-6, rtol=2e-5, noise=None):
-    """sd_np: the net's fp32 weights (numpy, _NOVIEW_ORDER names); rb [n,8], z [n,S] fp32 CPU tensors;
+def flip_aware_check(sd_np, rb, z, white_bkgd, ray_loss, gpu_grads, what, thr=5e-6, rtol=2e-5, noise=None):
+    """sd_np: the net's fp32 weights (numpy; vallina_NeRF names, with or without view directions); rb [n,8|11], z [n,S] fp32 CPU tensors;
     ray_loss(ret, idx) -> scalar: the loss restricted to rays idx (ret: rgb_map disp_map acc_map raw of those rays) - the
     total loss must be the sum of it over a partition of the rays; gpu_grads: {name: tensor}.  Returns (#flips, #risky)."""
     n, S = z.shape
     names = [k for k in gpu_grads if gpu_grads[k] is not None]
     sd = {k: v.double().requires_grad_(True) for k, v in O.to_torch_sd(sd_np).items()}
     pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]
-    e_all = O.embed(pts.reshape(-1, 3), 10).double().reshape(n, S, -1)
+    e_all = O.embed(pts.reshape(-1, 3), 10)
+    if rb.shape[1] > 8:                                   # nerf/run.py:80-82: the view directions, expanded per sample
+        e_all = torch.cat([e_all, O.embed(rb[:, None, -3:].expand(pts.shape).reshape(-1, 3), 4)], -1)
+    e_all = e_all.double().reshape(n, S, -1)
 
     def grads(idx, flips=None, pres=None):
         for v in sd.values():
@@ -61,7 +74,7 @@ def noview_flip_aware_check(sd_np, rb, z, white_bkgd, ray_loss, gpu_grads, what,
     cols = []
     for l, row, u in risky:
         ray = torch.tensor([row // S])
-        f = torch.zeros((S, 256), dtype=torch.bool)
+        f = torch.zeros((S, pres[l].shape[1]), dtype=torch.bool)
         f[row % S, u] = True
         cols.append(grads(ray, {l: f}) - grads(ray))
     ours = torch.cat([gpu_grads[k].detach().double().cpu().reshape(-1) for k in names])
@@ -85,3 +98,6 @@ def noview_flip_aware_check(sd_np, rb, z, white_bkgd, ray_loss, gpu_grads, what,
         assert d <= rtol * scale, f"{what} {k}: {d:.3e} of {scale:.3e} ({d / scale:.2e}) after accounting for {flips} ReLU flips of {len(risky)} risky units"
         o += m
     return flips, len(risky)
+
+
+noview_flip_aware_check = flip_aware_check

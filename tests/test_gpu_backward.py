@@ -122,6 +122,10 @@ def test_training_step_matches_autograd(dev):
     loss = img2mse(ret["rgb_map"], target.to(dev))
     loss.backward()
     _grad_check({k: p.grad for k, p in net_c.named_parameters()}, {k: v.grad for k, v in oc.items()}, "coarse-only step", rtol=5e-4)
+    from flipcheck import flip_aware_check                # float64 truth + exact ReLU-flip accounting: 2e-5 (tests/flipcheck.py)
+    mse48 = lambda r, idx: ((r["rgb_map"] - target[idx].to(r["raw"])) ** 2).sum() / (3 * 48)
+    fl = flip_aware_check(sd_c, rb, O.coarse_z(rb[:, 6:7], rb[:, 7:8], 64), True, mse48, {k: p.grad for k, p in net_c.named_parameters()}, "coarse-only step vs float64")
+    print(f"\n[parity] coarse-only training step (48 x 64 rows): every gradient within 2e-5 of float64; ReLU flips (of risky units) {fl}")
     # ---- coarse + fine, both losses; the resampled depths are detached (nerf/run.py:398) - feed the oracle OUR z_fine
     # so that the comparison is not about sample_pdf's conditioning
     net_c.zero_grad()
@@ -142,6 +146,8 @@ def test_training_step_matches_autograd(dev):
     raw_g = q(pts.to(dev), rb[:, -3:].to(dev), net_f)
     img2mse(ray.raw2outputs(raw_g, z_fine.to(dev), rb[:, 3:6].to(dev), 0, True)[0], target.to(dev)).backward()
     _grad_check({k: p.grad for k, p in net_f.named_parameters()}, {k: v.grad for k, v in of.items()}, "fine net, fixed depths", rtol=5e-4)
+    fl = flip_aware_check(sd_f, rb, z_fine, True, mse48, {k: p.grad for k, p in net_f.named_parameters()}, "fine net on the op path, fixed depths, vs float64")
+    print(f"\n[parity] op-path fine net (48 x 192 rows): every gradient within 2e-5 of float64; ReLU flips (of risky units) {fl}")
     # an Adam step on these gradients changes the render (weights are re-packed automatically)
     opt = torch.optim.Adam(list(net_f.parameters()), lr=5e-4, betas=(0.9, 0.999))
     with torch.no_grad():
@@ -226,6 +232,12 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
     pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z_fine.cpu()[..., None]
     torch.mean((O.raw2outputs(O.run_network(of, pts, rb[:, -3:]), z_fine.cpu(), rb[:, 3:6], 0., True)[0] - target) ** 2).backward()
     _grad_check({k: p.grad for k, p in net_f.named_parameters()}, {k: v.grad for k, v in of.items()}, "fused fine pass vs autograd", rtol=5e-4)
+    # ... and to 2e-5 of each tensor's max against the float64 evaluation, with the ReLU flips of near-zero units accounted
+    # for exactly (tests/flipcheck.py): what is left of the 5e-4 above is conditioning of the fp32 oracle, not arithmetic
+    from flipcheck import flip_aware_check
+    fl = flip_aware_check(sd_f, rb, z_fine.cpu(), True, lambda r, idx: ((r["rgb_map"] - target[idx].to(r["raw"])) ** 2).sum() / (3 * 48),
+                          {k: p.grad for k, p in net_f.named_parameters()}, "fused fine pass vs float64 autograd")
+    print(f"\n[parity] fused training fine pass (48 x 192 rows, view directions): every gradient within 2e-5 of float64; ReLU flips (of risky units) {fl}")
     # what falls back to the op path still trains: raw requested, or more samples than the fused backward holds in LDS
     ret = render.render_rays(rb.to(dev)[:8], net_c, q, 64, retraw=True, N_importance=0, white_bkgd=True)
     assert ret["raw"].requires_grad
