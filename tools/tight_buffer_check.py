@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     sys.path.insert(0, p)
 CASES = ["rays", "embed", "pass_static", "pass_dnerf", "pass_noview", "raw2outputs", "sample_pdf", "mlp_static", "mlp_dnerf", "mlp_noview",
-         "query", "sample_coarse", "train_static", "train_dnerf", "pass_x3_static", "pass_x3_dnerf"]
+         "query", "sample_coarse", "train_static", "train_dnerf", "train_noview", "pass_x3_static", "pass_x3_dnerf"]
 if len(sys.argv) < 2 or sys.argv[1] == "list":
     print(" ".join(CASES))
     sys.exit(0)
@@ -132,7 +132,7 @@ with torch.no_grad():
         z, pts = render.sample_coarse(rb, 64, True, tight(torch.rand((N, 64), device=dev)), want_pts=True)
         tight(z); tight(pts)
         assert bool(torch.isfinite(pts).all())
-if case in ("train_static", "train_dnerf"):
+if case in ("train_static", "train_dnerf", "train_noview"):
     # one training step at 4096 rays: act / grad [786 432, 2432], xs [.., 96], masks - all tight by their size
     n = 4096
     K, c2w = synth.lego_camera(400, 400)
@@ -146,6 +146,15 @@ if case in ("train_static", "train_dnerf"):
                                            N_samples=64, N_importance=128, network_fine=nets[1], white_bkgd=True, perturb=1., raw_noise_std=1., retraw=True)
         (((rgb - tgt) ** 2).mean() + ((ex["rgb0"] - tgt) ** 2).mean() + 1e-3 * ex["raw"].sum()).backward()
         assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for m in nets for p in m.parameters())
+    elif case == "train_noview":
+        nets = [noview_net().train(), noview_net().train()]
+        q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=None)
+        rgb, disp, acc, ex = render.render(400, 400, K, rays=rays, ndc=False, near=2., far=6., use_viewdirs=False, network_fn=nets[0], network_query_fn=q,
+                                           N_samples=64, N_importance=128, network_fine=nets[1], white_bkgd=True, perturb=1., raw_noise_std=1., retraw=True)
+        assert ex["raw"].shape == (n, 192, 5)
+        (((rgb - tgt) ** 2).mean() + ((ex["rgb0"] - tgt) ** 2).mean() + 1e-3 * ex["raw"].sum()).backward()
+        used = [p for m in nets for k, p in m.named_parameters() if k.startswith(("pts_linears", "output_linear"))]
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0 for p in used)
     else:
         dn = dnerf_net().train()
         qd = lambda inputs, viewdirs, ts, network_fn: render_dnerf.run_network(inputs, viewdirs, ts, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
