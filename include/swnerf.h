@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 105
+#define SWNERF_VERSION 106
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -157,6 +157,16 @@ int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int
 int swnerf_gemm_tn_fused(const float* A, int lda, const float* B, int ldb, int64_t M, float* C, int ldc, float* bias,
                          const float* B2, int ldb2, int Ni2, float* C2, int ldc2,
                          const float* A2, int lda2, int No2, float* C3, int ldc3, float* bias3, void* stream);
+/* Several swnerf_gemm_tn_fused problems over the SAME M rows (the weight-gradient GEMMs of one row chunk of a training step:
+ * loss.backward() of nerf/run.py:700) as ONE launch: the workgroups are dealt out over the items in proportion to their work,
+ * so the chunk pays one launch ramp and one atomic epilogue instead of one per layer.  Field meaning as the arguments of
+ * swnerf_gemm_tn_fused (riders may be NULL).  Results equal the separate calls' (split-K atomics add in a different order). */
+typedef struct swnerf_gemm_item {
+    const float* A; int lda; const float* B; int ldb; float* C; int ldc; float* bias;
+    const float* B2; int ldb2; int Ni2; float* C2; int ldc2;
+    const float* A2; int lda2; int No2; float* C3; int ldc3; float* bias3;
+} swnerf_gemm_item;
+int swnerf_gemm_tn_group(const swnerf_gemm_item* items /*HOST*/, int n_items, int64_t M, void* stream);
 
 /* ---- training path of DirectTemporalNeRF (autograd of model.py:128-151; the loss of
  * d_nerf/run_dnerf.py:690-725 needs d/d(position_delta) too).  The forward is the composition the

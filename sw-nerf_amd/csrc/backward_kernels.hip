@@ -281,7 +281,7 @@ struct GemmFused {
 };
 
 template <bool HB2, bool HA2>
-__global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) {
+__device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slice) {
     const GemmTN& P = F.g;
     extern __shared__ __attribute__((aligned(16))) float gd_lds[];           // [2][GD_BUF_FLOATS] [2][B2] [2][A2]
     float* b2s = gd_lds + 2 * GD_BUF_FLOATS;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) {
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int o0 = 64 * (w & 3), i0 = 64 * (w >> 2);
-    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int64_t m0 = (int64_t)slice * P.rows_per_wg;
     const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
     const int nslab = (mlen + GD_SLAB - 1) / GD_SLAB;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)gd_lds);
@@ -434,6 +434,26 @@ __global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) {
             if (hp == 0 && i < F.No2) atomicAdd(F.bias3 + i, bs3);
         }
     }
+}
+
+template <bool HB2, bool HA2>
+__global__ void __launch_bounds__(1024) gemm_tn_dma_kernel(GemmFused F) { gemm_dma_body<HB2, HA2>(F, (int)blockIdx.x); }
+
+// SEVERAL such GEMMs of one row chunk as ONE launch (swnerf_gemm_tn_group): the weight-gradient GEMMs of a chunk are
+// independent, and every launch costs ~70 us that the matrix pipe idles through (ramp, and an epilogue of 64 K float atomics
+// per workgroup that all workgroups reach at the same moment) - 15-24 % of a 393 216-row launch.  Here the ~256 workgroups
+// of ONE launch are dealt out over the items in proportion to their work (an item with a rider does 5 MFMAs per 4), each
+// covering a longer row slice of its item: one ramp and one epilogue per chunk instead of one per layer.
+#define GG_MAX 16
+struct GemmGroup { int n; int wg0[GG_MAX + 1]; GemmFused it[GG_MAX]; };      // wg0: first workgroup of item k (prefix sums)
+__global__ void __launch_bounds__(1024) gemm_tn_dma_group_kernel(GemmGroup G) {
+    int k = 0;
+    while (k + 1 < G.n && (int)blockIdx.x >= G.wg0[k + 1]) ++k;               // wave-uniform: scalar
+    const GemmFused& F = G.it[k];
+    const int slice = (int)blockIdx.x - G.wg0[k];
+    if (F.B2) gemm_dma_body<true, false>(F, slice);
+    else if (F.A2) gemm_dma_body<false, true>(F, slice);
+    else gemm_dma_body<false, false>(F, slice);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -608,6 +628,66 @@ extern "C" int swnerf_gemm_tn_fused(const float* A, int lda, const float* B, int
     if (!rc && B2) rc = swnerf_gemm_tn(A, lda, 256, B2, ldb2, Ni2, M, C2, ldc2, nullptr, stream);
     if (!rc && A2) rc = swnerf_gemm_tn(A2, lda2, No2, B, ldb, 256, M, C3, ldc3, bias3, stream);
     return rc;
+}
+
+// Up to 16 of the 256 x 256 GEMMs (each with at most one rider) over the SAME M rows as one launch; see
+// gemm_tn_dma_group_kernel.  Items that do not qualify for the DMA kernel (alignment, M < 4096, both riders) go through
+// swnerf_gemm_tn_fused one by one.
+extern "C" int swnerf_gemm_tn_group(const swnerf_gemm_item* items, int n_items, int64_t M, void* stream) {
+    if (M == 0 || n_items == 0) return 0;
+    if (!items || n_items < 0 || M < 0) return sw_fail(SWNERF_E_ARG, "gemm_tn_group: NULL items / negative count");
+    GemmGroup G;
+    G.n = 0;
+    int weight[GG_MAX];
+    bool any_b2 = false, any_a2 = false;
+    auto single = [&](const swnerf_gemm_item& q) {
+        return swnerf_gemm_tn_fused(q.A, q.lda, q.B, q.ldb, M, q.C, q.ldc, q.bias, q.B2, q.ldb2, q.Ni2, q.C2, q.ldc2,
+                                    q.A2, q.lda2, q.No2, q.C3, q.ldc3, q.bias3, stream);
+    };
+    for (int k = 0; k < n_items; ++k) {
+        const swnerf_gemm_item& q = items[k];
+        if (!q.A || !q.B || !q.C || q.lda < 256 || q.ldb < 256 || q.ldc < 256)
+            return sw_fail(SWNERF_E_ARG, "gemm_tn_group: item %d: bad main operands (lda=%d ldb=%d ldc=%d)", k, q.lda, q.ldb, q.ldc);
+        if (q.B2 && (!q.C2 || q.Ni2 < 1 || q.Ni2 > 64 || q.ldb2 < q.Ni2 || q.ldc2 < q.Ni2)) return sw_fail(SWNERF_E_ARG, "gemm_tn_group: item %d: bad B2 rider", k);
+        if (q.A2 && (!q.C3 || q.No2 < 1 || q.No2 > 32 || q.lda2 < q.No2 || q.ldc3 < 256)) return sw_fail(SWNERF_E_ARG, "gemm_tn_group: item %d: bad A2 rider", k);
+        const bool aligned = (q.lda % 4 == 0) && (q.ldb % 4 == 0) && (((uintptr_t)q.A | (uintptr_t)q.B) % 16 == 0);
+        if (!aligned || M < 4096 || (q.B2 && q.A2) || G.n == GG_MAX || getenv("SWNERF_GEMM_GROUP_OFF") != nullptr) {
+            int rc = single(q);
+            if (rc) return rc;
+            continue;
+        }
+        GemmFused& F = G.it[G.n];
+        F.g.A = q.A; F.g.lda = q.lda; F.g.No = 256; F.g.B = q.B; F.g.ldb = q.ldb; F.g.Ni = 256; F.g.C = q.C; F.g.ldc = q.ldc; F.g.bias = q.bias; F.g.M = M;
+        F.B2 = q.B2; F.ldb2 = q.ldb2; F.Ni2 = q.Ni2; F.C2 = q.C2; F.ldc2 = q.ldc2;
+        F.A2 = q.A2; F.lda2 = q.lda2; F.No2 = q.No2; F.C3 = q.C3; F.ldc3 = q.ldc3; F.bias3 = q.bias3;
+        static const int rider_w = getenv("SWNERF_GG_RIDER_W") ? atoi(getenv("SWNERF_GG_RIDER_W")) : 6;
+        weight[G.n] = (q.B2 || q.A2) ? rider_w : 4;         // 5 MFMAs per 4 and a shorter unroll: 1.2-1.3x alone, 6 : 4 measured best in a group
+        any_b2 |= q.B2 != nullptr; any_a2 |= q.A2 != nullptr;
+        ++G.n;
+    }
+    if (G.n == 0) return 0;
+    if (G.n == 1) {                                          // nothing to group
+        GemmFused F = G.it[0];
+        return gemm_dma_launch(F, stream);
+    }
+    // ~256 workgroups (one per CU: each needs >128 KB of LDS) dealt out in proportion to the items' work, whole 32-row slabs each
+    int wsum = 0;
+    for (int k = 0; k < G.n; ++k) wsum += weight[k];
+    int total = 0;
+    G.wg0[0] = 0;
+    for (int k = 0; k < G.n; ++k) {
+        int64_t nwg = (256 * (int64_t)weight[k]) / wsum;
+        if (nwg < 1) nwg = 1;
+        int64_t rows = ((M + nwg - 1) / nwg + GD_SLAB - 1) / GD_SLAB * GD_SLAB;
+        nwg = (M + rows - 1) / rows;
+        G.it[k].g.rows_per_wg = rows;
+        total += (int)nwg;
+        G.wg0[k + 1] = total;
+    }
+    const size_t lds = (2 * GD_BUF_FLOATS + (any_b2 ? 2 * GD_B2_FLOATS : 0) + (any_a2 ? 2 * GD_A2_FLOATS : 0)) * sizeof(float);
+    // (a body without the B2 rider places the A2 slabs right behind the main buffers: any_b2's space is then simply unused)
+    hipLaunchKernelGGL(gemm_tn_dma_group_kernel, dim3((unsigned)total), dim3(1024), lds, (hipStream_t)stream, G);
+    return sw_check(hipGetLastError(), "gemm_tn_group launch");
 }
 
 extern "C" int swnerf_gemm_tn(const float* A, int lda, int No, const float* B, int ldb, int Ni, int64_t M,

@@ -112,15 +112,45 @@ def _st(st):
 
 def _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias):
     """C[:, c_col:c_col+Ni] += A[:, a_col:a_col+No]^T . B[:, b_col:b_col+Ni];  bias += column sums of that A block"""
+    if isinstance(st, _Group):
+        if No == 256 and Ni == 256:
+            return _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias)
+        st = st.st                                            # narrow shapes keep their own launches
     _lib.check(L.swnerf_gemm_tn(A.data_ptr() + 4 * a_col, A.stride(0), No, B.data_ptr() + 4 * b_col, B.stride(0), Ni, M,
                                 C.data_ptr() + 4 * c_col, C.stride(0), _lib.ptr(bias), _st(st)), "gemm_tn")
 
 
+class _Group:
+    """Collects the 256 x 256 weight-gradient GEMMs of one row chunk and launches them as ONE kernel (swnerf_gemm_tn_group:
+    one ramp and one atomic epilogue per chunk instead of one per layer); `st` is where that launch goes."""
+
+    def __init__(self, st):
+        self.st, self.items = st, []
+
+    def launch(self, L, M):
+        if self.items:
+            arr = (_lib.GemmItem * len(self.items))(*self.items)
+            _lib.check(L.swnerf_gemm_tn_group(arr, len(self.items), M, _st(self.st)), "gemm_tn_group")
+            self.items = []
+
+
+# SWNERF_GEMM_GROUP: 1 (default) = the rider-free 256 x 256 GEMMs of a chunk share a launch (_chunk_gemms; equal work per
+# workgroup); 0 = one launch per layer.  (The two GEMMs with riders can join a group - swnerf_gemm_tn_group takes them - but
+# their workgroups run 1.2-1.3x longer and that measured no better: profiles/r03/gemm_group.md.)
+GEMM_GROUP = os.environ.get("SWNERF_GEMM_GROUP", "1") != "0"      # 0: one launch per layer (round 2 / early round 3)
+
+
 def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col=0, Ni2=0, C2=None, c2_col=0,
                    A2=None, a2_col=0, No2=0, C3=None, bias3=None):
-    """256x256 block C[:, c_col:] += A[:, a_col:]^T . B[:, b_col:] with the riders of swnerf_gemm_tn_fused."""
+    """256x256 block C[:, c_col:] += A[:, a_col:]^T . B[:, b_col:] with the riders of swnerf_gemm_tn_fused.
+    st a _Group: queued for the chunk's grouped launch."""
     off = lambda T_, col: None if T_ is None else T_.data_ptr() + 4 * col
     ld = lambda T_: 0 if T_ is None else T_.stride(0)
+    if isinstance(st, _Group):
+        st.items.append(_lib.GemmItem(off(A, a_col), ld(A), off(B, b_col), ld(B), off(C, c_col), ld(C), _lib.ptr(bias),
+                                      off(B2, b2_col), ld(B2), Ni2, off(C2, c2_col), ld(C2),
+                                      off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3)))
+        return
     _lib.check(L.swnerf_gemm_tn_fused(off(A, a_col), ld(A), off(B, b_col), ld(B), M, off(C, c_col), ld(C), _lib.ptr(bias),
                                       off(B2, b2_col), ld(B2), Ni2, off(C2, c2_col), ld(C2),
                                       off(A2, a2_col), ld(A2), No2, off(C3, 0), ld(C3), _lib.ptr(bias3), _st(st)), "gemm_tn_fused")
@@ -173,22 +203,51 @@ def _slot_buffers(device):
     return slots[:16384].view(256, 64), slots[16384:32768].view(256, 64), slots[32768:].view(128, 32)
 
 
-def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slot_bufs, rgb4=None):
+def _trunk_plain_grads(L, st, M, grad, act, g):
+    """The six rider-free 256 x 256 weight gradients of an 8 x 256 trunk (layers 1-4, 6, 7; model.py:39-47 reversed)."""
+    for l in (1, 2, 3, 4, 6, 7):
+        _gemm_tn(L, st, M, grad, 256 * l, 256, act, 256 * (l - 1), 256, g[2 * l], 0, g[2 * l + 1])
+
+
+def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slot_bufs, rgb4=None, part="all"):
     """The same 12 weight gradients for the FUSED training pass (accumulating: call once per row chunk): the
     encodings come as xs [M, 96] in operand slot order (64 slots gamma(x), 32 slots gamma(d); csrc/swnerf_common.h
     sw_xs_col), so the three GEMMs against them accumulate slot-ordered columns into `slot_bufs`, which
     _unslot_weight_grads moves to their reference columns at the end.  Every operand is 16-byte aligned here
-    (x[:, :63] with ld 90 was not)."""
+    (x[:, :63] with ld 90 was not).  part: "plain" = the six rider-free 256 x 256 GEMMs only (for the chunk's grouped launch,
+    _chunk_gemms), "rest" = everything else, "all" = both."""
     c0s, c5s, cvs = slot_bufs
+    if part != "rest":
+        _trunk_plain_grads(L, st, M, grad, act, g)
+    if part == "plain":
+        return
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
-    mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
-    for l in (1, 2, 3, 4, 6, 7):
-        mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, g[2 * l], 0, g[2 * l + 1])
     _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
+    _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
+    mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
     mm(grad, 2304, 128, act, 2048, 256, g[16], 0, g[17])                       # views_linears.0 = [feature | dirs]
     mm(grad, 2304, 128, xs, 64, 32, cvs, 0, None)
-    _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
     _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
+
+
+def _chunk_gemms(L, fan, M, jobs):
+    """The weight-gradient GEMMs of one row chunk.  jobs: callables job(st, part).  With SWNERF_GEMM_GROUP (default) the
+    rider-free 256 x 256 GEMMs of all jobs go out first as ONE launch on the main stream, alone on the chip (its workgroups
+    run ~2.5 ms each: next to another kernel they would start in rounds and finish in rounds, with half the chip idle in
+    between - measured +2.8 ms on the step without view directions), then the rest fans out over the side streams."""
+    if GEMM_GROUP:
+        grp = _Group(ctypes.c_void_p(fan.main.cuda_stream))
+        for job in jobs:
+            job(grp, "plain")
+        grp.launch(L, M)
+        fan.fork()
+        for job in jobs:
+            job(fan, "rest")
+    else:
+        fan.fork()
+        for job in jobs:
+            job(fan, "all")
+    fan.join()                                               # before the next chunk's backward kernel overwrites grad / d_raw
 
 
 def _noview_slot_buffers(device):
@@ -198,16 +257,17 @@ def _noview_slot_buffers(device):
     return z[:16384].view(256, 64), z[16384:32768].view(256, 64), z[32768:34816].view(8, 256), z[34816:34824]
 
 
-def _noview_weight_grads_slots(L, st, M, grad, act, xs, d_raw8, Cpos, g, bufs):
+def _noview_weight_grads_slots(L, st, M, grad, act, xs, d_raw8, Cpos, g, bufs, part="all"):
     """dW / db of the 8x256 net without view directions (g: zeroed tensors in _NOVIEW_ORDER), accumulating per row chunk:
-    model.py:39-47,59-60 reversed.  grad / act columns 0..2047 = pts_linears.0..7; xs slots 0..63 = gamma(x)."""
+    model.py:39-47,59-60 reversed.  grad / act columns 0..2047 = pts_linears.0..7; xs slots 0..63 = gamma(x).  part as above."""
     c0s, c5s, w8, b8 = bufs
-    mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
-    mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
-    for l in (1, 2, 3, 4, 6, 7):
-        mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, g[2 * l], 0, g[2 * l + 1])
+    if part != "rest":
+        _trunk_plain_grads(L, st, M, grad, act, g)
+    if part == "plain":
+        return
     _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
-    mm(d_raw8, 0, 8, act, 1792, 256, w8, 0, b8)                                # output_linear (rows 0..out_ch-1)
+    _gemm_tn(L, st, M, grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                  # pts_linears.0
+    _gemm_tn(L, st, M, d_raw8, 0, 8, act, 1792, 256, w8, 0, b8)                # output_linear (rows 0..out_ch-1)
 
 
 def _noview_unslot(L, st, bufs, Lp, g):
@@ -234,17 +294,19 @@ def _deform_slot_buffers(device):
             z[40960:41984].view(4, 256), z[41984:41988])
 
 
-def _deform_weight_grads_slots(L, st, M, grad_d, act_d, xs_d, g_dx, Cpos, gd, bufs):
+def _deform_weight_grads_slots(L, st, M, grad_d, act_d, xs_d, g_dx, Cpos, gd, bufs, part="all"):
     """dW / db of the deformation net (`_time.0..7`, `_time_out`; gd: zeroed tensors in _DEFORM_ORDER) for the fused D-NeRF
     training pass, accumulating (one call per row chunk): xs_d [M, 96] = gamma(x) (64 slots) and gamma(t) (32 slots) in
-    operand slot order, g_dx [M, 4] = d dx with a zero 4th column (aligned: the 4-row form, 4th row dropped)."""
+    operand slot order, g_dx [M, 4] = d dx with a zero 4th column (aligned: the 4-row form, 4th row dropped).  part as above."""
     c0s, c5s, cts, w4, b4 = bufs
+    if part != "rest":
+        _trunk_plain_grads(L, st, M, grad_d, act_d, gd)
+    if part == "plain":
+        return
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
+    _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=xs_d, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # _time.5
     mm(grad_d, 0, 256, xs_d, 0, 64, c0s, 0, gd[1])                             # _time.0 = [gamma(x) | gamma(t)]
     mm(grad_d, 0, 256, xs_d, 64, 32, cts, 0, None)
-    for l in (1, 2, 3, 4, 6, 7):
-        mm(grad_d, 256 * l, 256, act_d, 256 * (l - 1), 256, gd[2 * l], 0, gd[2 * l + 1])
-    _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=xs_d, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # _time.5
     mm(g_dx, 0, 4, act_d, 1792, 256, w4, 0, b4)                                # _time_out (rows 0..2)
 
 

@@ -275,7 +275,7 @@ class _FusedPassTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan,
-                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot)
+                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot, _chunk_gemms)
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -313,12 +313,12 @@ class _FusedPassTrain(torch.autograd.Function):
             else:
                 _lib.check(L.swnerf_render_pass_backward(*common, *grads_in), "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            fan.fork()
             if nv:
-                _noview_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, g, slot_bufs)
+                job = lambda st_, part: _noview_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, g, slot_bufs, part=part)
             else:
-                _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, net.input_ch_views, g, slot_bufs, rgb4)
-            fan.join()                                           # before the next chunk's backward kernel overwrites grad / d_raw
+                job = lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch,
+                                                                  net.input_ch_views, g, slot_bufs, rgb4, part=part)
+            _chunk_gemms(L, fan, m, [job])
         if nv:
             _noview_unslot(L, st, slot_bufs, Lp, g)
         else:

@@ -119,7 +119,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
-                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan)
+                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan, _chunk_gemms)
         from . import render as _r
         rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
@@ -157,10 +157,9 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
                 _lib.ptr(sl(g_acc, r0, r1)), _lib.ptr(sl(g_raw, r0, r1)), _lib.ptr(grad), _lib.ptr(grad_d), _lib.ptr(d_raw), _lib.ptr(g_dx), st),
                 "render_pass_backward_dnerf")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            fan.fork()
-            _canon_weight_grads_slots(L, fan, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4)
-            _deform_weight_grads_slots(L, fan, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs)
-            fan.join()
+            _chunk_gemms(L, fan, m, [
+                lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4, part=part),
+                lambda st_, part: _deform_weight_grads_slots(L, st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs, part=part)])
         _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc)
         _rgb4_finish(gc, rgb4)
         _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)

@@ -607,3 +607,47 @@ def test_gemm_tn_fused_riders(dev, M):
     r3 = D[:, :3].double().T @ Bd
     assert float((C3 - r3.float()).abs().max()) <= tol(r3)
     assert float((b3 - D[:, :3].double().sum(0).float()).abs().max()) <= 2e-5 * float(D[:, :3].double().sum(0).abs().max() + 1)
+
+
+@pytest.mark.parametrize("M,n_plain", [(4096 + 37, 6), (40000, 1), (3000, 2), (98304, 14)])
+def test_gemm_tn_group(dev, M, n_plain):
+    """swnerf_gemm_tn_group - the 256 x 256 weight-gradient GEMMs of one row chunk as ONE launch, the workgroups dealt out
+    over the items - against torch in float64: plain items, one with the B2 rider (64 slot columns), one with the A2 rider
+    (column 3 of a [M,4] operand, with its bias), an item with BOTH riders (split off), ragged M (a last slab of 5 rows,
+    slices of unequal length), the small-M fallback, and accumulation into non-zero C (C += ...)."""
+    from swnerf import _lib, model
+    L = _lib.lib()
+    gen = torch.Generator(device="cpu").manual_seed(11 * M + n_plain)
+    A = torch.randn((M, 2432), generator=gen).to(dev)
+    B = torch.randn((M, 2432), generator=gen).to(dev)
+    X = torch.randn((M, 96), generator=gen).to(dev)
+    D = torch.randn((M, 4), generator=gen).to(dev)
+    tol = lambda ref: 2e-5 * float(ref.abs().max())
+    grp = model._Group(_lib.stream_of(A))
+    want = []
+    for k in range(n_plain):
+        a_col, b_col = 256 * (k % 9), 256 * ((k + 3) % 8)
+        C, bias = torch.ones((256, 256), device=dev), torch.full((256,), 2.0, device=dev)
+        model._gemm_tn(L, grp, M, A, a_col, 256, B, b_col, 256, C, 0, bias if k % 2 == 0 else None)
+        Ad, Bd = A[:, a_col:a_col + 256].double(), B[:, b_col:b_col + 256].double()
+        want.append((C, 1.0 + Ad.T @ Bd, f"plain {k}"))
+        if k % 2 == 0:
+            want.append((bias, 2.0 + Ad.sum(0), f"bias {k}"))
+    Ad, Bd = A[:, 1280:1536].double(), B[:, 1024:1280].double()
+    C5, c5s, b5 = torch.zeros((256, 319), device=dev), torch.zeros((256, 64), device=dev), torch.zeros(256, device=dev)
+    model._gemm_tn_fused(L, grp, M, A, 1280, B, 1024, C5, 63, b5, B2=X, b2_col=0, Ni2=64, C2=c5s, c2_col=0)
+    want += [(C5[:, 63:], Ad.T @ Bd, "B2 item main"), (c5s, Ad.T @ X[:, :64].double(), "B2 rider"), (b5, Ad.sum(0), "B2 item bias")]
+    Cf, C3, b3 = torch.zeros((256, 256), device=dev), torch.zeros((1, 256), device=dev), torch.zeros(1, device=dev)
+    model._gemm_tn_fused(L, grp, M, A, 2048, B, 1792, Cf, 0, None, A2=D, a2_col=3, No2=1, C3=C3, bias3=b3)
+    Af, Bf = A[:, 2048:2304].double(), B[:, 1792:2048].double()
+    want += [(Cf, Af.T @ Bf, "A2 item main"), (C3, D[:, 3:4].double().T @ Bf, "A2 rider"), (b3, D[:, 3].double().sum().reshape(1), "A2 bias")]
+    Cb, cbs, C3b, b3b = torch.zeros((256, 256), device=dev), torch.zeros((256, 32), device=dev), torch.zeros((3, 256), device=dev), torch.zeros(3, device=dev)
+    model._gemm_tn_fused(L, grp, M, A, 512, B, 256, Cb, 0, None, B2=X, b2_col=64, Ni2=32, C2=cbs, c2_col=0, A2=D, a2_col=0, No2=3, C3=C3b, bias3=b3b)
+    Ab, Bb = A[:, 512:768].double(), B[:, 256:512].double()
+    want += [(Cb, Ab.T @ Bb, "both riders main"), (cbs, Ab.T @ X[:, 64:96].double(), "both: B2"), (C3b, D[:, :3].double().T @ Bb, "both: A2"),
+             (b3b, D[:, :3].double().sum(0), "both: bias3")]
+    assert len(grp.items) == n_plain + 3
+    grp.launch(L, M)
+    assert not grp.items
+    for got, ref, what in want:
+        assert float((got.double() - ref).abs().max()) <= tol(ref) + 1e-4, f"{what} (M={M}): {float((got.double() - ref).abs().max()):.3e} of {float(ref.abs().max()):.3e}"

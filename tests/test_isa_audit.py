@@ -117,7 +117,7 @@ def test_weight_gradient_gemm_isa(tmp_path):
         body = asm[asm.index("\n" + name + ":"):]
         assert "scratch_" not in body[:body.index("s_endpgm")]
         seen += 1
-    assert seen == 12               # + the five wave grids of the skinny double-buffered kernel (gemm_tn_tiled_kernel)
+    assert seen == 13               # + the five wave grids of the skinny double-buffered kernel (gemm_tn_tiled_kernel) + the grouped launch
 
 
 def test_x3_kernels_isa(tmp_path):
