@@ -473,9 +473,8 @@ __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
 }
 
-// The same tail in the training passes: h7 (`in`, ReLU mask `mb`) is side-stored by feature_linear's segment, the
-// feature by the view layer's; the view hidden layer and its mask are stored on the spot (act_row / mask_tile:
-// trunk_pass).
+// The same tail in the fused training passes: h7 (`in`, ReLU mask `mb`) is side-stored by feature_linear's segment; the
+// view hidden layer and its mask are stored on the spot (act_row / mask_tile: trunk_pass).
 __device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], f32x16 (&out)[8], const f32x16& demb,
                                                  float (&rgb)[3], const float* hb_rgb, WStream& ws,
                                                  float* act_row, float* mask_tile, const f32x4& mb) {
@@ -485,7 +484,9 @@ __device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], f32x16 (
     for (int n = 0; n < 8; ++n) k9[n] = out[n];
     k9[8] = demb;
     f32x16 hv[4];
-    seg_mfma<4, 9, SEG_BIAS, 8>(hv, k9, ws, 1.f, SideStore{act_row + SW_ACT_FEAT, nullptr, mb});
+    // `feature` is NOT saved (act columns SW_ACT_FEAT.. stay unwritten): feature_linear has no activation, so the weight
+    // gradients on both sides of it follow from G = d pre_hv^T . h7 (swnerf/model.py _unslot_weight_grads)
+    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll

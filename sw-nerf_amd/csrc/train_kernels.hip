@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         mask_apply<4>(mask_take(mr), dhv);
         mask_fetch(mr, 7);
         seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
-        seg_mfma<8, 8, SEG_BIAS_SCALED, 8>(out, in, ws, dr[3], SideStore{grad_row + SW_ACT_FEAT, nullptr, nomask});
+        seg_mfma<8, 8, SEG_BIAS_SCALED>(out, in, ws, dr[3]);    // d feature is not written out: nothing reads it (model.py _unslot_weight_grads)
         }
 #pragma nounroll
         for (int l = 7; l >= 1; --l) {

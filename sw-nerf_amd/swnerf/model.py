@@ -134,10 +134,10 @@ class _Group:
             self.items = []
 
 
-# SWNERF_GEMM_GROUP: 1 (default) = the rider-free 256 x 256 GEMMs of a chunk share a launch (_chunk_gemms; equal work per
-# workgroup); 0 = one launch per layer.  (The two GEMMs with riders can join a group - swnerf_gemm_tn_group takes them - but
-# their workgroups run 1.2-1.3x longer and that measured no better: profiles/r03/gemm_group.md.)
-GEMM_GROUP = os.environ.get("SWNERF_GEMM_GROUP", "1") != "0"      # 0: one launch per layer (round 2 / early round 3)
+# SWNERF_GEMM_GROUP: 1 (default) = the 256 x 256 GEMMs of a chunk share a launch (_chunk_gemms); plain = the skip layer's GEMM
+# (gamma(x) rider: its workgroups run 1.2-1.3x longer) keeps its own launch; 0 = one launch per layer (profiles/r03/gemm_group.md)
+GEMM_GROUP = os.environ.get("SWNERF_GEMM_GROUP", "1") != "0"
+GROUP_RIDERS = os.environ.get("SWNERF_GEMM_GROUP", "1") != "plain"  # the skip layer's GEMM (gamma(x) rider) joins the group, at work weight 6 : 4      # 0: one launch per layer (round 2 / early round 3)
 
 
 def _gemm_tn_fused(L, st, M, A, a_col, B, b_col, C, c_col, bias, B2=None, b2_col=0, Ni2=0, C2=None, c2_col=0,
@@ -198,9 +198,13 @@ def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g, rgb4=None)
 
 
 def _slot_buffers(device):
-    """Zeroed slot-ordered accumulators for the three encoding GEMMs of the fused training pass."""
-    slots = torch.zeros(256 * 64 + 256 * 64 + 128 * 32, dtype=torch.float32, device=device)
-    return slots[:16384].view(256, 64), slots[16384:32768].view(256, 64), slots[32768:].view(128, 32)
+    """Zeroed accumulators of the fused training pass: slot-ordered columns for the three encoding GEMMs, G = d pre_hv^T . h7
+    [128, 256] (from which BOTH feature-related weight gradients follow, _unslot_weight_grads) and the 4-row form of
+    alpha_linear's gradient (A = d raw [rows, 4]; row 3) with its bias."""
+    z = torch.zeros(256 * 64 + 256 * 64 + 128 * 32 + 128 * 256 + 4 * 256 + 4, dtype=torch.float32, device=device)
+    o = [0, 16384, 32768, 36864, 69632, 70656, 70660]
+    return (z[o[0]:o[1]].view(256, 64), z[o[1]:o[2]].view(256, 64), z[o[2]:o[3]].view(128, 32),
+            z[o[3]:o[4]].view(128, 256), z[o[4]:o[5]].view(4, 256), z[o[5]:o[6]])
 
 
 def _trunk_plain_grads(L, st, M, grad, act, g):
@@ -216,17 +220,24 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slo
     _unslot_weight_grads moves to their reference columns at the end.  Every operand is 16-byte aligned here
     (x[:, :63] with ld 90 was not).  part: "plain" = the six rider-free 256 x 256 GEMMs only (for the chunk's grouped launch,
     _chunk_gemms), "rest" = everything else, "all" = both."""
-    c0s, c5s, cvs = slot_bufs
+    c0s, c5s, cvs, gfeat, a4w, a4b = slot_bufs
+    l5 = lambda: _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
     if part != "rest":
         _trunk_plain_grads(L, st, M, grad, act, g)
+        if part == "all" or GROUP_RIDERS:
+            l5()
     if part == "plain":
         return
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
-    _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
-    _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
+    if part == "rest" and not GROUP_RIDERS:
+        l5()
     mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
-    mm(grad, 2304, 128, act, 2048, 256, g[16], 0, g[17])                       # views_linears.0 = [feature | dirs]
-    mm(grad, 2304, 128, xs, 64, 32, cvs, 0, None)
+    # feature_linear has NO activation (model.py:50-51: feature = feature_linear(h); h = cat[feature, views]), so both weight
+    # gradients around it are linear images of ONE small matrix, G = d pre_hv^T . h7 [128, 256] (_unslot_weight_grads):
+    # neither `feature` nor d feature is ever stored or read, and the 256 x 256 GEMM of feature_linear is not run at all.
+    mm(grad, 2304, 128, act, 1792, 256, gfeat, 0, g[17])                       # G (+ views_linears.0.bias)
+    mm(grad, 2304, 128, xs, 64, 32, cvs, 0, None)                              # views_linears.0, gamma(d) slots
+    mm(d_out, 0, 4, act, 1792, 256, a4w, 0, a4b)                               # alpha_linear = row 3 of d raw^T . h7
     _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
 
 
@@ -261,11 +272,15 @@ def _noview_weight_grads_slots(L, st, M, grad, act, xs, d_raw8, Cpos, g, bufs, p
     """dW / db of the 8x256 net without view directions (g: zeroed tensors in _NOVIEW_ORDER), accumulating per row chunk:
     model.py:39-47,59-60 reversed.  grad / act columns 0..2047 = pts_linears.0..7; xs slots 0..63 = gamma(x).  part as above."""
     c0s, c5s, w8, b8 = bufs
+    l5 = lambda: _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
     if part != "rest":
         _trunk_plain_grads(L, st, M, grad, act, g)
+        if part == "all" or GROUP_RIDERS:
+            l5()
     if part == "plain":
         return
-    _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=xs, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # pts_linears.5
+    if part == "rest" and not GROUP_RIDERS:
+        l5()
     _gemm_tn(L, st, M, grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                  # pts_linears.0
     _gemm_tn(L, st, M, d_raw8, 0, 8, act, 1792, 256, w8, 0, b8)                # output_linear (rows 0..out_ch-1)
 
@@ -279,11 +294,24 @@ def _noview_unslot(L, st, bufs, Lp, g):
     g[17] = g[17] + b8[:oc]
 
 
-def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g):
-    c0s, c5s, cvs = slot_bufs
+def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g, params):
+    """Finish the canonical net's gradients of a fused training pass (params: its tensors in _CANON_ORDER): slot-ordered
+    columns to their reference columns, then everything that hangs on feature_linear from G = sum_rows d pre_hv (x) h7:
+      feature = W_f h7 + b_f   =>  d views_linears.0.weight[:, :256] = sum d pre_hv (x) feature = G W_f^T + db_hv (x) b_f
+      d feature = Wv_f^T d pre_hv  =>  d feature_linear.weight = sum d feature (x) h7 = Wv_f^T G,  d feature_linear.bias = Wv_f^T db_hv
+    (Wv_f = views_linears.0.weight[:, :256]; three 128 x 256 x 256 products per step instead of 2 KB of stores, 2 KB of loads
+    and 131 kFLOP per row), and alpha_linear from the 4-row form."""
+    c0s, c5s, cvs, gfeat, a4w, a4b = slot_bufs
     for cs, nslots, slot0, W, col0 in ((c0s, 64, 0, g[0], 0), (c5s, 64, 0, g[10], 0), (cvs, 32, 64, g[16], 256)):
         _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), cs.stride(0), cs.shape[0], slot0, nslots, Lp, Ld, W.data_ptr(), W.stride(0),
                                         col0, st), "unslot_grad")
+    f32 = lambda p_: p_.detach().float()
+    Wv_f, W_f, b_f = f32(params[16])[:, :256], f32(params[18]), f32(params[19])
+    g[16][:, :256] += torch.addmm(torch.outer(g[17], b_f), gfeat, W_f.t())
+    g[18] = g[18] + Wv_f.t() @ gfeat
+    g[19] = g[19] + Wv_f.t() @ g[17]
+    g[20] = g[20] + a4w[3:4]
+    g[21] = g[21] + a4b[3:4]
 
 
 def _deform_slot_buffers(device):
@@ -299,12 +327,16 @@ def _deform_weight_grads_slots(L, st, M, grad_d, act_d, xs_d, g_dx, Cpos, gd, bu
     training pass, accumulating (one call per row chunk): xs_d [M, 96] = gamma(x) (64 slots) and gamma(t) (32 slots) in
     operand slot order, g_dx [M, 4] = d dx with a zero 4th column (aligned: the 4-row form, 4th row dropped).  part as above."""
     c0s, c5s, cts, w4, b4 = bufs
+    l5 = lambda: _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=xs_d, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # _time.5
     if part != "rest":
         _trunk_plain_grads(L, st, M, grad_d, act_d, gd)
+        if part == "all" or GROUP_RIDERS:
+            l5()
     if part == "plain":
         return
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
-    _gemm_tn_fused(L, st, M, grad_d, 1280, act_d, 1024, gd[10], Cpos, gd[11], B2=xs_d, b2_col=0, Ni2=64, C2=c5s, c2_col=0)   # _time.5
+    if part == "rest" and not GROUP_RIDERS:
+        l5()
     mm(grad_d, 0, 256, xs_d, 0, 64, c0s, 0, gd[1])                             # _time.0 = [gamma(x) | gamma(t)]
     mm(grad_d, 0, 256, xs_d, 64, 32, cts, 0, None)
     mm(g_dx, 0, 4, act_d, 1792, 256, w4, 0, b4)                                # _time_out (rows 0..2)

@@ -322,7 +322,7 @@ class _FusedPassTrain(torch.autograd.Function):
         if nv:
             _noview_unslot(L, st, slot_bufs, Lp, g)
         else:
-            _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g)
+            _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g, params)
             _rgb4_finish(g, rgb4)
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
@@ -381,8 +381,9 @@ def coarse_pass_resampled(ray_batch, net, N_samples, N_importance, *, want, u=No
 
 
 TRAIN_FUSED_MAX_SAMPLES = 256      # include/swnerf.h: swnerf_render_pass_train
-TRAIN_BWD_CHUNK_ROWS = 393216      # rows of the gradient buffer alive at once in the fused backward (3.8 GB); each chunk costs one
-                                   # atomic epilogue per GEMM (~44 us), so not smaller than needed
+# rows of the gradient buffer alive at once in the fused backward (393 216 rows = 3.8 GB); each chunk costs a backward-kernel
+# tail, one grouped GEMM launch and the narrow GEMMs' tail, so not smaller than needed
+TRAIN_BWD_CHUNK_ROWS = int(os.environ.get("SWNERF_TRAIN_BWD_CHUNK_ROWS", "393216"))
 
 
 def _rng_inputs(N, N_samples, N_importance, perturb, raw_noise_std, pytest, dev):

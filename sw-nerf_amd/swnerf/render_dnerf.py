@@ -160,7 +160,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
             _chunk_gemms(L, fan, m, [
                 lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4, part=part),
                 lambda st_, part: _deform_weight_grads_slots(L, st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs, part=part)])
-        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc)
+        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc, params[:24])
         _rgb4_finish(gc, rgb4)
         _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)
         g = gc + gd
