@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 106
+#define SWNERF_VERSION 107
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -336,6 +336,15 @@ int swnerf_render_pass_backward_dnerf(const float* packed_bwd_fused, const float
  * W[o][col0 + column(slot0 + f)] = Cs[o][f] for every real slot f; pad slots are dropped. */
 int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nslots, int L_pos, int L_dir,
                        float* W, int ldw, int col0, void* stream);
+/* The fused training pass stores neither `feature` nor d feature and does not run feature_linear's weight-gradient GEMM
+ * (feature_linear has no activation, model.py:50-51).  From G [128,256] = sum_rows d pre_hv (x) h7 (swnerf_gemm_tn of the
+ * gradient rows' view-hidden columns against h7), db_hv [128] (its bias output) and the CURRENT weights this adds
+ *   dWv[u][o] += sum_i G[u][i] W_f[o][i] + db_hv[u] b_f[o]      (d views_linears.0.weight[:, :256]; Wv/dWv: [128, ld >= 256])
+ *   dW_f[o][i] += sum_u Wv[u][o] G[u][i],   db_f[o] += sum_u Wv[u][o] db_hv[u]      (d feature_linear.weight / .bias)
+ *   dW_alpha[i] += a4w[3][i],  db_alpha += a4b[3]      (alpha_linear from the 4-row form: a4w [4,256] = d raw^T . h7, a4b [4]) */
+int swnerf_feature_finish(const float* G, const float* db_hv, const float* Wv, int ldwv, const float* W_f, const float* b_f,
+                          const float* a4w, const float* a4b, float* dWv, int ld_dwv, float* dW_f, float* db_f,
+                          float* dW_alpha, float* db_alpha, void* stream);
 /* ... for xs_d: slots 64..95 hold gamma(t) (L_time bands) instead of gamma(d) */
 int swnerf_unslot_grad_time(const float* Cs, int ld_s, int rows_w, int nslots, int L_time, float* W, int ldw, int col0, void* stream);
 

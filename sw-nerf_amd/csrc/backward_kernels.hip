@@ -759,6 +759,58 @@ extern "C" int swnerf_unslot_grad(const float* Cs, int ld_s, int rows, int slot0
     return sw_check(hipGetLastError(), "unslot_grad launch");
 }
 
+// ---------------------------------------------------------------------------------------------
+// feature_linear has no activation (model.py:50-51), so the fused training pass never stores `feature` or d feature and never
+// runs feature_linear's 256 x 256 weight-gradient GEMM: with G = sum_rows d pre_hv (x) h7 [128, 256] (one narrow GEMM) and
+// db_hv = sum_rows d pre_hv,
+//   d views_linears.0.weight[:, :256] += G . W_f^T + db_hv (x) b_f      (feature = W_f h7 + b_f)
+//   d feature_linear.weight          += Wv_f^T . G                      (d feature = Wv_f^T d pre_hv; Wv_f = views_linears.0.weight[:, :256])
+//   d feature_linear.bias            += Wv_f^T . db_hv
+// and alpha_linear's gradient is row 3 of the 4-row form (A = d raw [rows, 4]).  25 MFLOP once per backward pass: one small launch.
+__global__ void __launch_bounds__(256) feature_finish_kernel(const float* G, const float* db_hv, const float* Wv, int ldwv, const float* W_f,
+                                                             const float* b_f, const float* a4w, const float* a4b, float* dWv, int ld_dwv,
+                                                             float* dW_f, float* db_f, float* dW_alpha, float* db_alpha) {
+    __shared__ float sh[256];
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (b < 128) {                                           // row u = b of d views_linears.0.weight[:, :256]; thread = output column o
+        sh[t] = G[b * 256 + t];
+        __syncthreads();
+        const float* w = W_f + (size_t)t * 256;
+        float acc = 0.f;
+        for (int i = 0; i < 256; i += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + i);
+            acc = fmaf(sh[i], w4[0], acc); acc = fmaf(sh[i + 1], w4[1], acc); acc = fmaf(sh[i + 2], w4[2], acc); acc = fmaf(sh[i + 3], w4[3], acc);
+        }
+        dWv[(size_t)b * ld_dwv + t] += acc + db_hv[b] * b_f[t];
+    } else if (b < 384) {                                    // row o = b - 128 of d feature_linear.weight; thread = column i
+        const int o = b - 128;
+        if (t < 128) sh[t] = Wv[(size_t)t * ldwv + o];
+        __syncthreads();
+        float acc = 0.f;
+        for (int u = 0; u < 128; ++u) acc = fmaf(sh[u], G[u * 256 + t], acc);
+        dW_f[(size_t)o * 256 + t] += acc;
+        if (t == 0) {
+            float bb = 0.f;
+            for (int u = 0; u < 128; ++u) bb = fmaf(sh[u], db_hv[u], bb);
+            db_f[o] += bb;
+        }
+    } else {
+        dW_alpha[t] += a4w[3 * 256 + t];
+        if (t == 0) db_alpha[0] += a4b[3];
+    }
+}
+
+extern "C" int swnerf_feature_finish(const float* G, const float* db_hv, const float* Wv, int ldwv, const float* W_f, const float* b_f,
+                                     const float* a4w, const float* a4b, float* dWv, int ld_dwv, float* dW_f, float* db_f,
+                                     float* dW_alpha, float* db_alpha, void* stream) {
+    if (!G || !db_hv || !Wv || !W_f || !b_f || !a4w || !a4b || !dWv || !dW_f || !db_f || !dW_alpha || !db_alpha || ldwv < 256 || ld_dwv < 256)
+        return sw_fail(SWNERF_E_ARG, "feature_finish: NULL pointer or a leading dimension below 256");
+    if (((uintptr_t)W_f) % 16) return sw_fail(SWNERF_E_ARG, "feature_finish: feature_linear.weight must be 16-byte aligned");
+    hipLaunchKernelGGL(feature_finish_kernel, dim3(385), dim3(256), 0, (hipStream_t)stream, G, db_hv, Wv, ldwv, W_f, b_f, a4w, a4b, dWv, ld_dwv,
+                       dW_f, db_f, dW_alpha, db_alpha);
+    return sw_check(hipGetLastError(), "feature_finish launch");
+}
+
 // xs_d of the fused D-NeRF training pass carries gamma(t) in its third k-tile: slot f (0..31) -> sw_time_col
 __global__ void __launch_bounds__(256) unslot_time_kernel(const float* Cs, int ld_s, int rows, int nslots, int Lt, float* W, int ldw, int col0) {
     const int idx = blockIdx.x * 256 + threadIdx.x;

@@ -305,13 +305,11 @@ def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g, params):
     for cs, nslots, slot0, W, col0 in ((c0s, 64, 0, g[0], 0), (c5s, 64, 0, g[10], 0), (cvs, 32, 64, g[16], 256)):
         _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), cs.stride(0), cs.shape[0], slot0, nslots, Lp, Ld, W.data_ptr(), W.stride(0),
                                         col0, st), "unslot_grad")
-    f32 = lambda p_: p_.detach().float()
-    Wv_f, W_f, b_f = f32(params[16])[:, :256], f32(params[18]), f32(params[19])
-    g[16][:, :256] += torch.addmm(torch.outer(g[17], b_f), gfeat, W_f.t())
-    g[18] = g[18] + Wv_f.t() @ gfeat
-    g[19] = g[19] + Wv_f.t() @ g[17]
-    g[20] = g[20] + a4w[3:4]
-    g[21] = g[21] + a4b[3:4]
+    f32 = lambda p_: p_.detach() if (p_.dtype == torch.float32 and p_.is_contiguous()) else p_.detach().float().contiguous()
+    Wv, W_f, b_f = f32(params[16]), f32(params[18]), f32(params[19])
+    _lib.check(L.swnerf_feature_finish(_lib.ptr(gfeat), _lib.ptr(g[17]), _lib.ptr(Wv), Wv.stride(0), _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w),
+                                       _lib.ptr(a4b), _lib.ptr(g[16]), g[16].stride(0), _lib.ptr(g[18]), _lib.ptr(g[19]), _lib.ptr(g[20]),
+                                       _lib.ptr(g[21]), st), "feature_finish")
 
 
 def _deform_slot_buffers(device):
