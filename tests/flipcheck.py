@@ -86,8 +86,12 @@ def flip_aware_check(sd_np, rb, z, white_bkgd, ray_loss, gpu_grads, what, thr=5e
         Dm, units = Dm[:, live], [risky[i] for i in torch.nonzero(live)[:, 0].tolist()]
         if units:
             c = torch.from_numpy(np.linalg.lstsq(Dm.numpy(), diff.numpy()[:, None], rcond=None)[0][:, 0])
-            cr = c.round()
-            bad = ((c - cr).abs() > 0.05) | (cr < 0) | (cr > 1)
+            cr = c.round().clamp(0, 1)
+            # a coefficient off 0 / 1 only matters if its column is large enough to be told from fp32 summation noise: a unit whose
+            # flip moves no tensor by a quarter of the tolerance fits that noise with any coefficient (the residual check below
+            # still holds every tensor to rtol with the rounded coefficients)
+            amb = (c - cr).abs() * Dm.abs().max(0).values
+            bad = ((c - cr).abs() > 0.05) & (amb > 0.25 * rtol * truth.abs().max())
             assert not bool(bad.any()), f"{what}: flip coefficients {c[bad].tolist()} are not 0 / 1 (units {[units[i] for i in torch.nonzero(bad)[:, 0].tolist()]})"
             diff = diff - Dm @ cr
             flips = int(cr.sum())

@@ -2,6 +2,8 @@
 the float64 evaluation of the oracle with exact ReLU-flip accounting (tests/flipcheck.py): ray counts that are not multiples
 of 4, sample counts that are not multiples of 32, lindisp, stratified jitter, raw noise, white background, 4 / 5 output
 channels, backward chunks of a few rays, a gradient on every output.  Seeded: the same cases every run."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,9 +40,9 @@ def test_random_training_shapes(views, monkeypatch):
     used = lambda net: {k: p.grad for k, p in net.named_parameters() if views or k.startswith(("pts_linears", "output_linear"))}
     worst_flips = 0
     with torch.enable_grad():
-        for case in range(10):
+        for case in range(int(os.environ.get("SWNERF_TRAIN_RANDOM_CASES", "10"))):     # a soak: set it to a few hundred
             n, S = int(rng.integers(1, 41)), int(rng.choice([2, 3, 17, 31, 32, 33, 48, 64, 65, 96, 127]))
-            hier = case >= 6
+            hier = case % 10 >= 6
             Ni = int(rng.choice([1, 16, 40, 128])) if hier else 0
             S = max(S, 3) if hier else S
             if S + Ni > 256:
