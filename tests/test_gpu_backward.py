@@ -651,3 +651,25 @@ def test_gemm_tn_group(dev, M, n_plain):
     assert not grp.items
     for got, ref, what in want:
         assert float((got.double() - ref).abs().max()) <= tol(ref) + 1e-4, f"{what} (M={M}): {float((got.double() - ref).abs().max()):.3e} of {float(ref.abs().max()):.3e}"
+
+
+def test_feature_finish_kernel(dev):
+    """swnerf_feature_finish against the formulas in float64: d views_linears.0.weight[:, :256] += G W_f^T + db_hv (x) b_f,
+    d feature_linear.weight += Wv_f^T G, d feature_linear.bias += Wv_f^T db_hv, alpha_linear from row 3 of the 4-row form;
+    accumulating into non-zero gradients, Wv with its real leading dimension (283)."""
+    from swnerf import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    r = lambda *s: torch.randn(s, generator=gen).to(dev)
+    G, db_hv, Wv, W_f, b_f, a4w, a4b = r(128, 256), r(128), r(128, 283), r(256, 256), r(256), r(4, 256), r(4)
+    dWv, dW_f, db_f, dWa, dba = r(128, 283), r(256, 256), r(256), r(1, 256), r(1)
+    want = (dWv.double().clone(), dW_f.double() + Wv[:, :256].double().t() @ G.double(), db_f.double() + Wv[:, :256].double().t() @ db_hv.double(),
+            dWa.double() + a4w[3:4].double(), dba.double() + a4b[3:4].double())
+    want[0][:, :256] += G.double() @ W_f.double().t() + torch.outer(db_hv.double(), b_f.double())
+    _lib.check(L.swnerf_feature_finish(_lib.ptr(G), _lib.ptr(db_hv), _lib.ptr(Wv), 283, _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w), _lib.ptr(a4b),
+                                       _lib.ptr(dWv), 283, _lib.ptr(dW_f), _lib.ptr(db_f), _lib.ptr(dWa), _lib.ptr(dba), _lib.stream_of(G)), "feature_finish")
+    for got, ref, what in zip((dWv, dW_f, db_f, dWa, dba), want, ("dWv", "dW_f", "db_f", "dW_alpha", "db_alpha")):
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), what
+    with pytest.raises(RuntimeError):
+        _lib.check(L.swnerf_feature_finish(None, _lib.ptr(db_hv), _lib.ptr(Wv), 283, _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w), _lib.ptr(a4b),
+                                           _lib.ptr(dWv), 283, _lib.ptr(dW_f), _lib.ptr(db_f), _lib.ptr(dWa), _lib.ptr(dba), _lib.stream_of(G)), "feature_finish")
