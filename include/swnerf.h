@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 107
+#define SWNERF_VERSION 108
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -345,6 +345,15 @@ int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nsl
 int swnerf_feature_finish(const float* G, const float* db_hv, const float* Wv, int ldwv, const float* W_f, const float* b_f,
                           const float* a4w, const float* a4b, float* dWv, int ld_dwv, float* dW_f, float* db_f,
                           float* dW_alpha, float* db_alpha, void* stream);
+/* The five narrow weight-gradient products of the canonical net's fused training pass in ONE pass over M rows (instead of five
+ * swnerf_gemm_tn calls that read h7, d pre_hv and the xs rows twice each).  grad / act: the fused pass's gradient and activation
+ * rows [M, ld >= 2432] (columns: d pre_0 0..255, d pre_hv 2304..2431; h7 1792..2047, hv 2304..2431), xs [M, 96], d_out [M, 4].
+ * Accumulates (+=): c0s [256,64] = d pre_0^T xs[:, :64];  cvs [128,32] = d pre_hv^T xs[:, 64:96];  G [128,256] = d pre_hv^T h7;
+ * a4w [4,256] = d_out^T h7;  rgb4 [4,128] = d_out^T hv;  b_l0 [256], b_hv [128], a4b [4], rgb4b [4] = the column sums of d pre_0,
+ * d pre_hv and d_out (each may be NULL). */
+int swnerf_canon_narrow_grads(const float* grad, int ldg, const float* act, int lda, const float* xs, const float* d_out, int64_t M,
+                              float* c0s, float* cvs, float* G, float* a4w, float* rgb4, float* b_l0, float* b_hv, float* a4b,
+                              float* rgb4b, void* stream);
 /* ... for xs_d: slots 64..95 hold gamma(t) (L_time bands) instead of gamma(d) */
 int swnerf_unslot_grad_time(const float* Cs, int ld_s, int rows_w, int nslots, int L_time, float* W, int ldw, int col0, void* stream);
 

@@ -760,6 +760,175 @@ extern "C" int swnerf_unslot_grad(const float* Cs, int ld_s, int rows, int slot0
 }
 
 // ---------------------------------------------------------------------------------------------
+// The FIVE narrow weight-gradient products of the canonical net's fused training pass in ONE pass over the rows
+// (swnerf_canon_narrow_grads).  As separate GEMMs they read 2.1 GB per 393 216-row chunk at ~3.2 TB/s with the matrix pipe idle
+// (G and alpha_linear both read h7, G and the gamma(d) columns both read d pre_hv, pts_linears.0 and the gamma(d) columns
+// both read the xs rows); together they are 64 accumulator tiles - exactly a 256 x 256 GEMM's - over 1.35 GB:
+//   c0s [256, 64] += d pre_0^T . xs[:, :64]      pts_linears.0, gamma(x) slots            waves 8..11, 2 x 2 tiles each
+//   cvs [128, 32] += d pre_hv^T . xs[:, 64:96]   views_linears.0, gamma(d) slots          wave 12, 4 x 1
+//   G   [128,256] += d pre_hv^T . h7             (swnerf_feature_finish)                  waves 0..7, 2 x 2
+//   a4w [4, 256]  += d raw^T . h7                alpha_linear = row 3                     waves 13, 14, 1 x 4
+//   rgb4 [4, 128] += d raw^T . hv                rgb_linear = rows 0..2                   wave 15, 1 x 4
+// and the column sums of d pre_0, d pre_hv and d raw (the biases).  16-row slabs of all six operands (55 KB), double buffered,
+// filled by LDS-DMA; one barrier per slab; every wave issues 4 MFMAs per k-pair.
+#define N5_SLAB 16
+#define N5_A0 0                                   // d pre_0   [16][256]
+#define N5_B1 (N5_SLAB * 256)                     // h7        [16][256]
+#define N5_A1 (2 * N5_SLAB * 256)                 // d pre_hv  [16][128]
+#define N5_B2 (N5_A1 + N5_SLAB * 128)             // hv        [16][128]
+#define N5_B0 (N5_B2 + N5_SLAB * 128)             // xs        [16][96]
+#define N5_A2 (N5_B0 + N5_SLAB * 96)              // d raw     [16][4]  (the DMA instruction writes 1 KiB: 256 floats reserved)
+#define N5_BUF (N5_A2 + 256)
+// (A three-deep ring for the two 1-KiB-per-row operands - 145 KB of LDS, two of their slabs in flight - measured the same
+// 0.58 ms per 393 216 rows: the kernel is not bound by the latency of the one slab in flight but by the per-slab barrier and
+// issue overhead of 16-row slabs, 5.4 us per slab against 3.7 us of MFMAs; 32-row slabs do not fit the LDS.)
+struct Narrow5 {
+    const float* grad; int ldg; const float* act; int lda; const float* xs; const float* d_out;
+    int64_t M; int64_t rows_per_wg;
+    float* c0s; float* cvs; float* G; float* a4w; float* rgb4; float* b_l0; float* b_hv; float* a4b; float* rgb4b;
+};
+
+__global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
+    extern __shared__ __attribute__((aligned(16))) float n5_lds[];          // [2][N5_BUF]
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
+    const int nslab = (mlen + N5_SLAB - 1) / N5_SLAB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)n5_lds);
+    // DMA duties of wave w per slab: row w of d pre_0 and of h7; two 512-B rows of d pre_hv (w < 8) or hv (w >= 8); 1 KiB of
+    // the slab's (contiguous) xs rows (w < 6); the d raw rows (w == 15).  Rows past the slice are clamped to its last row.
+    auto issue = [&](int sl) {
+        const int r0 = sl * N5_SLAB;
+        const unsigned buf = lds0 + (unsigned)((sl & 1) * N5_BUF * 4);
+        auto rowc = [&](int r) { return min(r0 + r, mlen - 1); };           // slice-relative, clamped
+        const int64_t rw = m0 + rowc(w);
+        ws_dma(reinterpret_cast<const char*>(P.grad + rw * P.ldg), (unsigned)lane * 16u, buf + (unsigned)((N5_A0 + w * 256) * 4));
+        ws_dma(reinterpret_cast<const char*>(P.act + rw * P.lda + 1792), (unsigned)lane * 16u, buf + (unsigned)((N5_B1 + w * 256) * 4));
+        {
+            const int k = w & 7, ra = rowc(2 * k), rb = rowc(2 * k + 1);
+            const float* base = (w < 8 ? P.grad + (m0 + ra) * P.ldg : P.act + (m0 + ra) * P.lda) + 2304;
+            const unsigned pitch = (unsigned)((w < 8 ? P.ldg : P.lda) * 4);
+            const unsigned voff = (unsigned)(lane & 31) * 16u + (lane >> 5 ? (unsigned)(rb - ra) * pitch : 0u);
+            ws_dma(reinterpret_cast<const char*>(base), voff, buf + (unsigned)(((w < 8 ? N5_A1 : N5_B2) + k * 256) * 4));
+        }
+        if (w < 6) {                                                         // xs rows are dense (384 B): flat KiB w of the slab
+            const int flat = w * 1024 + lane * 16, r = flat / 384, off = flat - r * 384;
+            const int ra = rowc(0);
+            ws_dma(reinterpret_cast<const char*>(P.xs + (m0 + ra) * SW_XS_LD), (unsigned)((rowc(r) - ra) * 384 + off), buf + (unsigned)((N5_B0 + w * 256) * 4));
+        }
+        if (w == 15) {
+            const int ra = rowc(0);
+            ws_dma(reinterpret_cast<const char*>(P.d_out + (m0 + ra) * 4), (unsigned)((rowc(min(lane, N5_SLAB - 1)) - ra) * 16), buf + (unsigned)(N5_A2 * 4));
+        }
+    };
+    // ONE code path for all waves (role branches around the MFMAs made hipcc copy and spill the accumulators): tile k of wave w
+    // multiplies columns acol[k].. of its A operand (LDS offset asrc, row pitch ap, alim valid columns per 32: 4 for d raw) by
+    // columns bcol[k].. of its B operand - all wave-uniform scalars
+    int asrc, ap, alim = 32, bsrc, bp, acol[4], bcol[4];
+    if (w < 8) {                                             // G: A = d pre_hv tiles 2p, 2p+1; B = h7 tiles 2q, 2q+1
+        asrc = N5_A1; ap = 128; bsrc = N5_B1; bp = 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acol[k] = 64 * (w & 1) + 32 * (k >> 1); bcol[k] = 64 * (w >> 1) + 32 * (k & 1); }
+    } else if (w < 12) {                                     // pts_linears.0: A = d pre_0 tiles 2(w-8), +1; B = xs tiles 0, 1
+        asrc = N5_A0; ap = 256; bsrc = N5_B0; bp = SW_XS_LD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acol[k] = 64 * (w - 8) + 32 * (k >> 1); bcol[k] = 32 * (k & 1); }
+    } else if (w == 12) {                                    // gamma(d) columns: A = d pre_hv tiles 0..3; B = xs tile 2
+        asrc = N5_A1; ap = 128; bsrc = N5_B0; bp = SW_XS_LD;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acol[k] = 32 * k; bcol[k] = 64; }
+    } else {                                                 // d raw (4 columns) x h7 tiles 4(w-13).. (w = 13, 14) or hv tiles 0..3 (w = 15)
+        asrc = N5_A2; ap = 4; alim = 4; bsrc = w < 15 ? N5_B1 : N5_B2; bp = w < 15 ? 256 : 128;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acol[k] = 0; bcol[k] = (w < 15 ? 128 * (w - 13) : 0) + 32 * k; }
+    }
+    const bool acolumn = i < alim;
+    f32x16 acc[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    issue(0);
+#pragma nounroll
+    for (int sl = 0; sl < nslab; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+        if (sl + 1 < nslab) issue(sl + 1);
+        const float* As = n5_lds + (sl & 1) * N5_BUF + asrc + (acolumn ? i : 0);
+        const float* Bs = n5_lds + (sl & 1) * N5_BUF + bsrc + i;
+        const int valid = mlen - sl * N5_SLAB;
+        // operands of k-pair s+1 are read while the MFMAs of k-pair s run
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = As[hp * ap + acol[k]]; b[k] = Bs[hp * bp + bcol[k]]; }
+#pragma unroll 2
+        for (int s = 0; s < N5_SLAB / 2; ++s) {
+            const int row = 2 * s + hp;
+            const bool ok = acolumn && row < valid;
+            float c[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; }
+            const int nr = min(row + 2, N5_SLAB - 1);         // (the last iteration re-reads the slab's last rows: unused)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = As[nr * ap + acol[k]]; b[k] = Bs[nr * bp + bcol[k]]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bs[k] += c[k];
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[k], d[k], acc[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C/D map: register r of lane (j = i, h = hp) of tile k is row acol[k] + frow(r,h) of the A operand's columns, column bcol[k] + j
+    // of the B operand's (relative to the product's block)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32, 64);          // rows 2s and 2s+1 sit in the two lane halves
+    float* C; int ldc, rlim = 256, cshift = 0;
+    if (w < 8) { C = P.G; ldc = 256; }
+    else if (w < 12) { C = P.c0s; ldc = 64; }
+    else if (w == 12) { C = P.cvs; ldc = 32; cshift = 64; }
+    else if (w < 15) { C = P.a4w; ldc = 256; rlim = 4; }
+    else { C = P.rgb4; ldc = 128; rlim = 4; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = acol[k] + sw_frow(r, hp);
+            if (o < rlim) atomicAdd(C + (size_t)o * ldc + bcol[k] - cshift + i, acc[k][r]);
+        }
+    // column sums of the A operands: one wave per A tile writes them (tiles k = 0 and k = 2 of a 2 x 2 block hold different A tiles)
+    if (hp == 0) {
+        if (w < 2 && P.b_hv) { atomicAdd(P.b_hv + acol[0] + i, bs[0]); atomicAdd(P.b_hv + acol[2] + i, bs[2]); }
+        if (w >= 8 && w < 12 && P.b_l0) { atomicAdd(P.b_l0 + acol[0] + i, bs[0]); atomicAdd(P.b_l0 + acol[2] + i, bs[2]); }
+        if (w == 13 && P.a4b && i < 4) atomicAdd(P.a4b + i, bs[0]);
+        if (w == 15 && P.rgb4b && i < 4) atomicAdd(P.rgb4b + i, bs[0]);
+    }
+}
+
+extern "C" int swnerf_canon_narrow_grads(const float* grad, int ldg, const float* act, int lda, const float* xs, const float* d_out, int64_t M,
+                                         float* c0s, float* cvs, float* G, float* a4w, float* rgb4, float* b_l0, float* b_hv, float* a4b,
+                                         float* rgb4b, void* stream) {
+    if (M == 0) return 0;
+    if (!grad || !act || !xs || !d_out || !c0s || !cvs || !G || !a4w || !rgb4 || M < 0 || ldg < SW_ACT_LD || lda < SW_ACT_LD)
+        return sw_fail(SWNERF_E_ARG, "canon_narrow_grads: NULL pointer, negative M or a leading dimension below %d", SW_ACT_LD);
+    if (((uintptr_t)grad | (uintptr_t)act | (uintptr_t)xs | (uintptr_t)d_out) % 16 || ldg % 4 || lda % 4)
+        return sw_fail(SWNERF_E_ARG, "canon_narrow_grads: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    Narrow5 P;
+    P.grad = grad; P.ldg = ldg; P.act = act; P.lda = lda; P.xs = xs; P.d_out = d_out; P.M = M;
+    P.c0s = c0s; P.cvs = cvs; P.G = G; P.a4w = a4w; P.rgb4 = rgb4; P.b_l0 = b_l0; P.b_hv = b_hv; P.a4b = a4b; P.rgb4b = rgb4b;
+    int64_t nwg = 256;
+    int64_t rows = ((M + nwg - 1) / nwg + N5_SLAB - 1) / N5_SLAB * N5_SLAB;
+    nwg = (M + rows - 1) / rows;
+    P.rows_per_wg = rows;
+    if (rows * (int64_t)(ldg > lda ? ldg : lda) * 4 >= (1LL << 31)) return sw_fail(SWNERF_E_UNSUPP, "canon_narrow_grads: row slice too large for 32-bit byte offsets");
+    hipLaunchKernelGGL(narrow5_kernel, dim3((unsigned)nwg), dim3(1024), 2 * N5_BUF * sizeof(float), (hipStream_t)stream, P);
+    return sw_check(hipGetLastError(), "canon_narrow_grads launch");
+}
+
+// ---------------------------------------------------------------------------------------------
 // feature_linear has no activation (model.py:50-51), so the fused training pass never stores `feature` or d feature and never
 // runs feature_linear's 256 x 256 weight-gradient GEMM: with G = sum_rows d pre_hv (x) h7 [128, 256] (one narrow GEMM) and
 // db_hv = sum_rows d pre_hv,

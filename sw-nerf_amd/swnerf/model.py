@@ -137,6 +137,7 @@ class _Group:
 # SWNERF_GEMM_GROUP: 1 (default) = the 256 x 256 GEMMs of a chunk share a launch (_chunk_gemms); plain = the skip layer's GEMM
 # (gamma(x) rider: its workgroups run 1.2-1.3x longer) keeps its own launch; 0 = one launch per layer (profiles/r03/gemm_group.md)
 GEMM_GROUP = os.environ.get("SWNERF_GEMM_GROUP", "1") != "0"
+NARROW_FUSED = os.environ.get("SWNERF_NARROW_FUSED", "1") != "0"     # the canonical net's five narrow weight-gradient products as one kernel
 GROUP_RIDERS = os.environ.get("SWNERF_GEMM_GROUP", "1") != "plain"  # the skip layer's GEMM (gamma(x) rider) joins the group, at work weight 6 : 4      # 0: one launch per layer (round 2 / early round 3)
 
 
@@ -231,6 +232,13 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slo
     mm = lambda A, a_col, No, B, b_col, Ni, C, c_col, bias: _gemm_tn(L, st, M, A, a_col, No, B, b_col, Ni, C, c_col, bias)
     if part == "rest" and not GROUP_RIDERS:
         l5()
+    if (NARROW_FUSED and rgb4 is not None and d_out.stride(0) == 4 and grad.stride(0) == act.stride(0) and xs.stride(0) == 96
+            and not (grad.data_ptr() | act.data_ptr() | xs.data_ptr() | d_out.data_ptr()) % 16):
+        # the five narrow products below as ONE pass over the rows (csrc/backward_kernels.hip narrow5_kernel)
+        _lib.check(L.swnerf_canon_narrow_grads(_lib.ptr(grad), grad.stride(0), _lib.ptr(act), act.stride(0), _lib.ptr(xs), _lib.ptr(d_out), M,
+                                               _lib.ptr(c0s), _lib.ptr(cvs), _lib.ptr(gfeat), _lib.ptr(a4w), _lib.ptr(rgb4[0]), _lib.ptr(g[1]),
+                                               _lib.ptr(g[17]), _lib.ptr(a4b), _lib.ptr(rgb4[1]), _st(st)), "canon_narrow_grads")
+        return
     mm(grad, 0, 256, xs, 0, 64, c0s, 0, g[1])                                  # pts_linears.0
     # feature_linear has NO activation (model.py:50-51: feature = feature_linear(h); h = cat[feature, views]), so both weight
     # gradients around it are linear images of ONE small matrix, G = d pre_hv^T . h7 [128, 256] (_unslot_weight_grads):
@@ -241,7 +249,7 @@ def _canon_weight_grads_slots(L, st, M, grad, act, xs, d_out, Cpos, Cdir, g, slo
     _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
 
 
-def _chunk_gemms(L, fan, M, jobs):
+def _chunk_gemms(L, fan, M, jobs, rest_on_main=False):
     """The weight-gradient GEMMs of one row chunk.  jobs: callables job(st, part).  With SWNERF_GEMM_GROUP (default) the
     rider-free 256 x 256 GEMMs of all jobs go out first as ONE launch on the main stream, alone on the chip (its workgroups
     run ~2.5 ms each: next to another kernel they would start in rounds and finish in rounds, with half the chip idle in
@@ -251,9 +259,18 @@ def _chunk_gemms(L, fan, M, jobs):
         for job in jobs:
             job(grp, "plain")
         grp.launch(L, M)
+        # a job whose rest is ONE launch (swnerf_canon_narrow_grads) keeps it on the main stream, behind the group; what is
+        # left fans out over the side streams
+        on_main = rest_on_main if isinstance(rest_on_main, (list, tuple)) else [rest_on_main] * len(jobs)
+        for job, m_ in zip(jobs, on_main):
+            if m_:
+                job(grp.st, "rest")
+        if all(on_main):
+            return
         fan.fork()
-        for job in jobs:
-            job(fan, "rest")
+        for job, m_ in zip(jobs, on_main):
+            if not m_:
+                job(fan, "rest")
     else:
         fan.fork()
         for job in jobs:

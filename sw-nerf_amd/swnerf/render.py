@@ -275,7 +275,7 @@ class _FusedPassTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan,
-                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot, _chunk_gemms)
+                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot, _chunk_gemms, NARROW_FUSED)
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -318,7 +318,7 @@ class _FusedPassTrain(torch.autograd.Function):
             else:
                 job = lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch,
                                                                   net.input_ch_views, g, slot_bufs, rgb4, part=part)
-            _chunk_gemms(L, fan, m, [job])
+            _chunk_gemms(L, fan, m, [job], rest_on_main=NARROW_FUSED and not nv)
         if nv:
             _noview_unslot(L, st, slot_bufs, Lp, g)
         else:

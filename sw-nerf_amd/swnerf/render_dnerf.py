@@ -119,7 +119,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
         from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
-                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan, _chunk_gemms)
+                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan, _chunk_gemms, NARROW_FUSED)
         from . import render as _r
         rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
@@ -159,7 +159,8 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
             _chunk_gemms(L, fan, m, [
                 lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4, part=part),
-                lambda st_, part: _deform_weight_grads_slots(L, st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs, part=part)])
+                lambda st_, part: _deform_weight_grads_slots(L, st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs, part=part)],
+                rest_on_main=[NARROW_FUSED, False])
         _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc, params[:24])
         _rgb4_finish(gc, rgb4)
         _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)

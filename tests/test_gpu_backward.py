@@ -673,3 +673,27 @@ def test_feature_finish_kernel(dev):
     with pytest.raises(RuntimeError):
         _lib.check(L.swnerf_feature_finish(None, _lib.ptr(db_hv), _lib.ptr(Wv), 283, _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w), _lib.ptr(a4b),
                                            _lib.ptr(dWv), 283, _lib.ptr(dW_f), _lib.ptr(db_f), _lib.ptr(dWa), _lib.ptr(dba), _lib.stream_of(G)), "feature_finish")
+
+
+@pytest.mark.parametrize("M", [393216 // 8 + 5, 4099, 7, 16, 300000])
+def test_canon_narrow_grads_kernel(dev, M):
+    """swnerf_canon_narrow_grads - the five narrow weight-gradient products of the canonical net in one pass over the rows -
+    against torch in float64: ragged M (last slab of 5 / 3 / 7 rows, slices of unequal length, fewer rows than a slab),
+    accumulation into non-zero outputs, every bias."""
+    from swnerf import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device="cpu").manual_seed(3 * M + 1)
+    r = lambda *s: torch.randn(s, generator=gen).to(dev)
+    grad, act, xs, d_out = r(M, 2432), r(M, 2432), r(M, 96), r(M, 4)
+    outs = dict(c0s=r(256, 64), cvs=r(128, 32), G=r(128, 256), a4w=r(4, 256), rgb4=r(4, 128), b_l0=r(256), b_hv=r(128), a4b=r(4), rgb4b=r(4))
+    d = lambda t_: t_.double()
+    dp0, dphv, h7, hv = d(grad[:, :256]), d(grad[:, 2304:2432]), d(act[:, 1792:2048]), d(act[:, 2304:2432])
+    want = dict(c0s=d(outs["c0s"]) + dp0.T @ d(xs[:, :64]), cvs=d(outs["cvs"]) + dphv.T @ d(xs[:, 64:96]), G=d(outs["G"]) + dphv.T @ h7,
+                a4w=d(outs["a4w"]) + d(d_out).T @ h7, rgb4=d(outs["rgb4"]) + d(d_out).T @ hv, b_l0=d(outs["b_l0"]) + dp0.sum(0),
+                b_hv=d(outs["b_hv"]) + dphv.sum(0), a4b=d(outs["a4b"]) + d(d_out).sum(0), rgb4b=d(outs["rgb4b"]) + d(d_out).sum(0))
+    _lib.check(L.swnerf_canon_narrow_grads(_lib.ptr(grad), 2432, _lib.ptr(act), 2432, _lib.ptr(xs), _lib.ptr(d_out), M,
+                                           *[_lib.ptr(outs[k]) for k in ("c0s", "cvs", "G", "a4w", "rgb4", "b_l0", "b_hv", "a4b", "rgb4b")],
+                                           _lib.stream_of(grad)), "canon_narrow_grads")
+    for k, ref in want.items():
+        err = float((d(outs[k]) - ref).abs().max())
+        assert err <= 2e-5 * float(ref.abs().max()) + 1e-5, f"{k} (M={M}): {err:.3e} of {float(ref.abs().max()):.3e}"
