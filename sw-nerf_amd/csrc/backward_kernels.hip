@@ -798,9 +798,31 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)n5_lds);
     // DMA duties of wave w per slab: row w of d pre_0 and of h7; two 512-B rows of d pre_hv (w < 8) or hv (w >= 8); 1 KiB of
     // the slab's (contiguous) xs rows (w < 6); the d raw rows (w == 15).  Rows past the slice are clamped to its last row.
+    // Slabs are issued in order, so the row pointers of a FULL slab advance by constants and its per-lane offsets are fixed
+    // (all 16 waves run this right behind the barrier with the matrix pipe idle: 64-bit multiplies and a division per lane cost
+    // there); only the slice's last, partial slab clamps its rows to the last one.
+    const int kk = w & 7;
+    const char* p_a0 = reinterpret_cast<const char*>(P.grad + (m0 + w) * P.ldg);
+    const char* p_b1 = reinterpret_cast<const char*>(P.act + (m0 + w) * P.lda + 1792);
+    const char* p_s = reinterpret_cast<const char*>((w < 8 ? P.grad + (m0 + 2 * kk) * P.ldg : P.act + (m0 + 2 * kk) * P.lda) + 2304);
+    const char* p_x = reinterpret_cast<const char*>(P.xs + m0 * SW_XS_LD);
+    const char* p_d = reinterpret_cast<const char*>(P.d_out + m0 * 4);
+    const int64_t st_g = (int64_t)N5_SLAB * P.ldg * 4, st_a = (int64_t)N5_SLAB * P.lda * 4;
+    const unsigned pitch_s = (unsigned)((w < 8 ? P.ldg : P.lda) * 4);
+    const unsigned vo_s = (unsigned)(lane & 31) * 16u + (lane >> 5 ? pitch_s : 0u);
+    const unsigned vo_x = (unsigned)(w * 1024 + lane * 16), vo_d = (unsigned)(min(lane, N5_SLAB - 1) * 16);
     auto issue = [&](int sl) {
         const int r0 = sl * N5_SLAB;
         const unsigned buf = lds0 + (unsigned)((sl & 1) * N5_BUF * 4);
+        if (r0 + N5_SLAB <= mlen) {
+            ws_dma(p_a0, (unsigned)lane * 16u, buf + (unsigned)((N5_A0 + w * 256) * 4));
+            ws_dma(p_b1, (unsigned)lane * 16u, buf + (unsigned)((N5_B1 + w * 256) * 4));
+            ws_dma(p_s, vo_s, buf + (unsigned)(((w < 8 ? N5_A1 : N5_B2) + kk * 256) * 4));
+            if (w < 6) ws_dma(p_x, vo_x, buf + (unsigned)((N5_B0 + w * 256) * 4));
+            if (w == 15) ws_dma(p_d, vo_d, buf + (unsigned)(N5_A2 * 4));
+            p_a0 += st_g; p_b1 += st_a; p_s += (w < 8 ? st_g : st_a); p_x += N5_SLAB * SW_XS_LD * 4; p_d += N5_SLAB * 16;
+            return;
+        }
         auto rowc = [&](int r) { return min(r0 + r, mlen - 1); };           // slice-relative, clamped
         const int64_t rw = m0 + rowc(w);
         ws_dma(reinterpret_cast<const char*>(P.grad + rw * P.ldg), (unsigned)lane * 16u, buf + (unsigned)((N5_A0 + w * 256) * 4));
