@@ -32,6 +32,6 @@ for set in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch
   echo "pmc $name ok"
 done
 python3 tools/summarize_pmc_any.py $OUT/tr --skip 2 > $OUT/pmc_all.md
-grep -E "render_pass|gemm_tn|^\| kernel|^\|---" $OUT/pmc_all.md > $OUT/pmc_train_step.md
+grep -E "render_pass|gemm_tn|narrow5|feature_finish|^\| kernel|^\|---" $OUT/pmc_all.md > $OUT/pmc_train_step.md
 find $OUT -name '*.csv' -delete; find $OUT -type d -empty -delete
 cat $OUT/train_step_kernels.md | head -20; cat $OUT/pmc_train_step.md
