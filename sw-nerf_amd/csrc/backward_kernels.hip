@@ -878,23 +878,22 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
         if (sl + 1 < nslab) issue(sl + 1);
-        const float* As = n5_lds + (sl & 1) * N5_BUF + asrc + (acolumn ? i : 0);
-        const float* Bs = n5_lds + (sl & 1) * N5_BUF + bsrc + i;
         const int valid = mlen - sl * N5_SLAB;
-        // operands of k-pair s+1 are read while the MFMAs of k-pair s run
+        // operands of k-pair s+1 are read while the MFMAs of k-pair s run; one pointer per operand stream, advanced by two rows
+        // per k-pair (the last prefetch reads two rows past the slab: the next operand's region of the same buffer - unused)
+        int pa[4], pb[4];                                    // 32-bit LDS indices (generic pointers cost two registers each)
         float a[4], b[4];
+        const int ia = (sl & 1) * N5_BUF + asrc + (acolumn ? i : 0) + hp * ap, ib = (sl & 1) * N5_BUF + bsrc + i + hp * bp;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a[k] = As[hp * ap + acol[k]]; b[k] = Bs[hp * bp + bcol[k]]; }
+        for (int k = 0; k < 4; ++k) { pa[k] = ia + acol[k]; pb[k] = ib + bcol[k]; a[k] = n5_lds[pa[k]]; b[k] = n5_lds[pb[k]]; }
 #pragma unroll 2
         for (int s = 0; s < N5_SLAB / 2; ++s) {
-            const int row = 2 * s + hp;
-            const bool ok = acolumn && row < valid;
+            const bool ok = acolumn && (2 * s + hp) < valid;
             float c[4], d[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; }
-            const int nr = min(row + 2, N5_SLAB - 1);         // (the last iteration re-reads the slab's last rows: unused)
+            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; pa[k] += 2 * ap; pb[k] += 2 * bp; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = As[nr * ap + acol[k]]; b[k] = Bs[nr * bp + bcol[k]]; }
+            for (int k = 0; k < 4; ++k) { a[k] = n5_lds[pa[k]]; b[k] = n5_lds[pb[k]]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
