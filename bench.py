@@ -43,8 +43,17 @@ for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-FLOP_PER_ROW = 2 * 593408           # MACs of one (ray,sample) row through the 8x256 net
+FLOP_PER_ROW = 2 * 593408           # MACs of one (ray,sample) row through the 8x256 net AS THE REFERENCE RUNS IT
 FLOP_PER_ROW_DEFORM = 2 * 497152    # ... through the deformation net (D-NeRF, t != 0)
+# Round 4: feature_linear (256 x 256, no activation: model.py:49-53) is folded into views_linears.0 at pack time, so the
+# kernels EXECUTE 65 536 MACs per row fewer than the reference's algorithm.  Every roofline fraction in this file is
+# executed FLOPs / time / peak (it cannot exceed 1); the reference-algorithmic rate rides beside it as algorithmic_tflops.
+FLOP_EXEC_PER_ROW = 2 * (593408 - 65536)
+# training: forward (executed) + dX chain (RGB^T 16 + W_vf^T 128 + 7 x 256 weight steps x 4 MFMAs x 2048 MACs / 32 rows
+# = 495 616 MACs per row: no layer-0 / view-direction input gradients) + dW (the forward's shapes with G = d pre_hv^T h7
+# in place of feature_linear's GEMM = 527 872); the reference-algorithmic figure stays 3 x the forward
+FLOP_EXEC_TRAIN_PER_ROW = 2 * (527872 + 495616 + 527872)
+FLOP_EXEC_TRAIN_DEFORM_PER_ROW = 2 * (497152 + 7 * 65536 + 497152)        # deformation net: forward + L7..L1 transposed + dW
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); only used by --precision bf16x3 lines
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 N_RAND, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
@@ -183,6 +192,8 @@ def build_scene(cfg, dev, rank):
         sc["frame_time"] = 0.5
         sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM)
         sc["flop_per_fine_row"] = FLOP_PER_ROW + FLOP_PER_ROW_DEFORM
+        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM)
+        sc["exec_per_fine_row"] = FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM
         sc["kernel"] = "render_pass_kernel<true>"
     else:
         nets = []
@@ -202,6 +213,8 @@ def build_scene(cfg, dev, rank):
         sc["frame_time"] = None
         sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_ROW
         sc["flop_per_fine_row"] = FLOP_PER_ROW
+        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_PER_ROW
+        sc["exec_per_fine_row"] = FLOP_EXEC_PER_ROW
         sc["kernel"] = "render_pass_kernel<false>"
     sc["K"], sc["c2w"] = synth.lego_camera(sc["H"], sc["W"])
     return sc
@@ -218,8 +231,9 @@ def extra_configs(dev):
 
     from oracle import nerf_oracle as O
 
-    def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False, ref=None):
-        """ref: None, or callable(first 256 rows of fn()'s rgb on the GPU) -> the CPU oracle's rgb for the same rays
+    def timeit(name, fn, n_rays, flop_per_ray, reps, grad=False, ref=None, exec_per_ray=None):
+        """flop_per_ray: the reference-algorithmic FLOPs; exec_per_ray: the FLOPs the kernels execute (None: the same).
+        ref: None, or callable(first 256 rows of fn()'s rgb on the GPU) -> the CPU oracle's rgb for the same rays
         (the checker, outside the timed region): PSNR of the HIP render against it goes into the row.
         Untimed warm-up: at least two calls AND 0.25 s of them - after the seconds of GPU idle that every row's CPU-oracle
         check leaves behind, the first ~2 ms of GPU work run at a reduced clock (measured round 3,
@@ -243,8 +257,9 @@ def extra_configs(dev):
             torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / reps
         tf = n_rays * flop_per_ray / dt / 1e12
-        rows.append({"name": name, "ms": dt * 1e3, "rays_per_s": n_rays / dt, "algorithmic_tflops": tf,
-                     "frac": tf / PEAK_FP32_MFMA_TFLOPS, "reps": reps})
+        tfe = n_rays * (flop_per_ray if exec_per_ray is None else exec_per_ray) / dt / 1e12
+        rows.append({"name": name, "ms": dt * 1e3, "rays_per_s": n_rays / dt, "algorithmic_tflops": tf, "executed_tflops": tfe,
+                     "frac": tfe / PEAK_FP32_MFMA_TFLOPS, "reps": reps})
         if ref is not None:
             with torch.no_grad():
                 want = ref()
@@ -261,11 +276,11 @@ def extra_configs(dev):
     sd_c, sd_f = (O.to_torch_sd(sd_) for sd_ in st["sds_np"])
     rb1 = O.make_ray_batch(torch.from_numpy(o), torch.from_numpy(d), 2., 6.)
     timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50,
-           ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"])
+           ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"], exec_per_ray=64 * FLOP_EXEC_PER_ROW)
     # the north_star's own target line: lego (nerf/configs/lego.txt: half_res 400x400, N_rand = 1024, 64 + 128, two nets,
     # white_bkgd, use_viewdirs) - 1024 rays are exactly one wave per SIMD on 256 CUs: both launches run a single round
     timeit("north_star: lego 1024-ray batch x (64+128), two nets", lambda: render.render(400, 400, K4, rays=r1, **kw), 1024, st["flop_per_ray"], 50,
-           ref=lambda: O.render_rays(rb1, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+           ref=lambda: O.render_rays(rb1, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"], exec_per_ray=st["exec_per_ray"])
     # use_viewdirs=False - the reference's argparse default (utils.py:43, model.py:59-60, 8-column rays nerf/run.py:152-157):
     # the C2 batch through two nets WITHOUT the view branch (output_ch = 5), on the fused pass's own variant; FLOPs per row
     # = 2 x (63*256 + 4*256^2 + 319*256 + 2*256^2 + 256*5) = 984 576
@@ -297,13 +312,13 @@ def extra_configs(dev):
     kw3 = dict(kw, ndc=True, near=0., far=1., white_bkgd=False)
     rb3 = O.make_ray_batch(torch.from_numpy(o[:512]), torch.from_numpy(d[:512]), 0., 1., ndc=True, H=378, W=504, focal=float(Kf[0][0]))
     timeit("C3: fern-like NDC rays, 4096 x (64+128)", lambda: render.render(378, 504, Kf, rays=r3, **kw3), N_RAND, st["flop_per_ray"], 10,
-           ref=lambda: O.render_rays(rb3, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=False)["rgb_map"])
+           ref=lambda: O.render_rays(rb3, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=False)["rgb_map"], exec_per_ray=st["exec_per_ray"])
     lo, hi = synth.shard_range(800 * 800, 8, 3)
     rr4 = parallel.frame_renderer(800, 800, K8, c2w8, kw, device=dev)
     o8, d8 = O.get_rays(800, 800, K8, c2w8)
     rb4 = O.make_ray_batch(o8.reshape(-1, 3)[lo:lo + 512], d8.reshape(-1, 3)[lo:lo + 512], 2., 6.)
     timeit("C4 shard: rank 3 of 8 of the 800x800 frame, 80 000 rays incl. get_rays", lambda: rr4(lo, hi - lo), hi - lo, st["flop_per_ray"], 3,
-           ref=lambda: O.render_rays(rb4, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+           ref=lambda: O.render_rays(rb4, sd_c, sd_f, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"], exec_per_ray=st["exec_per_ray"])
     # the opt-in bf16x3 arithmetic (csrc/mlp_core_x3.h) on the same C4 shard: NOT the headline (that is fp32) - rays/s, the
     # PSNR against the same CPU oracle rays and against this library's fp32 render of the whole shard, and the bf16 MFMA
     # rate it sustains (3 MFMAs per product: 3 x the algorithmic FLOPs) against the 2.5 PFLOP/s dense bf16 peak
@@ -334,7 +349,8 @@ def extra_configs(dev):
         rb5 = O.make_ray_batch(o4.reshape(-1, 3)[lo5:lo5 + 256], d4.reshape(-1, 3)[lo5:lo5 + 256], 2., 6., frame_time=tv)
         timeit(f"C5 shard: D-NeRF rank 3 of 8 of the 400x400 frame, 20 000 rays, t={tv}", lambda: rr5(lo5, hi5 - lo5), hi5 - lo5,
                s5["flop_per_ray"] if tv else st["flop_per_ray"], 3,
-               ref=lambda rb5=rb5: O.render_rays_dnerf(rb5, sd_d, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"])
+               ref=lambda rb5=rb5: O.render_rays_dnerf(rb5, sd_d, N_SAMPLES, N_IMPORTANCE, white_bkgd=True)["rgb_map"],
+               exec_per_ray=s5["exec_per_ray"] if tv else st["exec_per_ray"])
     # ... and the D-NeRF shard at t = 0.5 in bf16x3 (deformation + canonical net in one pass; the fp32 row is two rows up)
     rr5 = parallel.frame_renderer(400, 400, s5["K"], s5["c2w"], s5["kw"], frame_time=0.5, device=dev)
     rb5 = O.make_ray_batch(o4.reshape(-1, 3)[lo5:lo5 + 256], d4.reshape(-1, 3)[lo5:lo5 + 256], 2., 6., frame_time=0.5)
@@ -374,7 +390,7 @@ def extra_configs(dev):
         opt.step()
     torch.cuda.reset_peak_memory_stats(dev)
     timeit("training step: 4096 rays x (64+128), two nets, mse(rgb)+mse(rgb0), backward, Adam (3x forward FLOPs)", train_step,
-           N_RAND, 3 * st["flop_per_ray"], 5, grad=True)
+           N_RAND, 3 * st["flop_per_ray"], 5, grad=True, exec_per_ray=(N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_TRAIN_PER_ROW)
     rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     for m in nets:
         m.eval()
@@ -423,7 +439,9 @@ def extra_configs(dev):
         opt_d.step()
     torch.cuda.reset_peak_memory_stats(dev)
     timeit("D-NeRF training step: 4096 rays x (64+128), one DirectTemporalNeRF at t=0.5, mse(rgb), backward, Adam", train_step_dnerf,
-           N_RAND, (N_SAMPLES + 3 * (N_SAMPLES + N_IMPORTANCE)) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM), 4, grad=True)
+           N_RAND, (N_SAMPLES + 3 * (N_SAMPLES + N_IMPORTANCE)) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM), 4, grad=True,
+           exec_per_ray=N_SAMPLES * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM)
+           + (N_SAMPLES + N_IMPORTANCE) * (FLOP_EXEC_TRAIN_PER_ROW + 2 * 32768 + FLOP_EXEC_TRAIN_DEFORM_PER_ROW))   # + the 128 d gamma(x+dx) steps
     rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     dn.eval()
     for p in dn.parameters():
@@ -573,7 +591,8 @@ def worker(args):
 
     ms_kernel = [fine_events[i].elapsed_time(fine_events[i + 1]) for i in range(0, len(fine_events), 2)]
     fine_ms = float(np.mean(ms_kernel)) if ms_kernel else float("nan")
-    fine_flop = n_local * S_FINE * sc["flop_per_fine_row"]
+    fine_flop = n_local * S_FINE * sc["exec_per_fine_row"]              # MFMA FLOPs the launch EXECUTES (feature_linear folded)
+    fine_flop_alg = n_local * S_FINE * sc["flop_per_fine_row"]          # ... the reference's algorithm would
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
@@ -610,7 +629,10 @@ def worker(args):
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)",
                      "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
-                     "step_frac": rays_per_step / world * sc["flop_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                     "flop_accounting": "executed: feature_linear (65 536 MACs/row, no activation) is folded into views_linears.0 at pack "
+                                        "time, 527 872 MACs/row run (+497 152 for the deformation net); algorithmic_* = the reference's 593 408",
+                     "algorithmic_flop_per_launch": fine_flop_alg, "algorithmic_tflops": fine_flop_alg / (fine_ms * 1e-3) / 1e12,
+                     "step_frac": rays_per_step / world * sc["exec_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
     }
     if x3:
         # the fine pass runs 3 bf16 MFMAs per product: price the matrix work it really does against the dense bf16 peak
@@ -657,7 +679,9 @@ def worker(args):
     if rank == 0 and world == 1 and not args.no_extra:
         render.PASS_HOOK = None
         result["extra"] = {"note": "measured after and outside the headline's timed region, same process and GPU; wall clock per "
-                                   "call incl. Python; frac = algorithmic MLP FLOPs / time / 157.3 TFLOP/s; psnr_vs_cpu_render_db = the "
+                                   "call incl. Python; frac = EXECUTED MLP FLOPs / time / 157.3 TFLOP/s (executed_tflops; feature_linear is folded into the view "
+                                   "layer, training rows count forward + dX chain + dW as run), algorithmic_tflops = the reference's FLOP count "
+                                   "(3 x forward for training) / time; psnr_vs_cpu_render_db = the "
                                    "HIP render against the CPU oracle's render of the first psnr_rays rays of that config",
                            "configs": extra_configs(dev)}
     if rank == 0:

@@ -452,17 +452,17 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
     ws.bias += SW_BIAS_TILE_FLOATS;
 }
 
-// ---- canonical tail: feature_linear (no activation) -> views_linears[0]+relu -> rgb_linear ---
+// ---- canonical tail: [feature_linear folded into] views_linears[0] + relu -> rgb_linear ---
 // `in` = relu(layer 7).  On return rgb[0..2] = raw rgb of row j on every lane (model.py:49-58).
-// hb_rgb: the head-bias tile (LDS) saved by the caller before FEAT: [b_alpha, b_r, b_g, b_b].
+// feature_linear has no activation, so the packed stream carries W_vf = Wv[:, :256] . W_f and b_vf = Wv[:, :256] . b_f + b_v
+// (swnerf_common.h SW_CANON_STEPS, pack_kernels.hip fold_views_kernel): ONE 4 x 9 segment on [h7 | gamma(d)].
+// hb_rgb: the head-bias tile (LDS) saved by the caller: [b_alpha, b_r, b_g, b_b].
 // demb: the view-direction k-tile (pe_dir), supplied by the caller.
-__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[8], const f32x16& demb,
-                                           float (&rgb)[3], const float* hb_rgb, WStream& ws) {
-    seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                  // feature = feature_linear(h)
+__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], const f32x16& demb, float (&rgb)[3], const float* hb_rgb, WStream& ws) {
     f32x16 k9[9];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = out[n];
-    k9[8] = demb;                                           // cat[feature, input_views]
+    for (int n = 0; n < 8; ++n) k9[n] = in[n];
+    k9[8] = demb;                                           // cat[h7, input_views]
     f32x16 hv[4];
     seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
@@ -473,20 +473,17 @@ __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], f32x16 (&out)[
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
 }
 
-// The same tail in the fused training passes: h7 (`in`, ReLU mask `mb`) is side-stored by feature_linear's segment; the
-// view hidden layer and its mask are stored on the spot (act_row / mask_tile: trunk_pass).
-__device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], f32x16 (&out)[8], const f32x16& demb,
-                                                 float (&rgb)[3], const float* hb_rgb, WStream& ws,
-                                                 float* act_row, float* mask_tile, const f32x4& mb) {
-    seg_mfma<8, 8, SEG_BIAS, 8>(out, in, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
+// The same tail in the fused training passes: h7 (`in`, ReLU mask `mb`) is side-stored by the view layer's segment, whose B
+// operand it is; the view hidden layer and its mask are stored on the spot (act_row / mask_tile: trunk_pass).  `feature` does
+// not exist: the weight gradients on both sides of feature_linear follow from G = d pre_hv^T . h7 (swnerf_feature_finish).
+__device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], const f32x16& demb, float (&rgb)[3], const float* hb_rgb,
+                                                 WStream& ws, float* act_row, float* mask_tile, const f32x4& mb) {
     f32x16 k9[9];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = out[n];
+    for (int n = 0; n < 8; ++n) k9[n] = in[n];
     k9[8] = demb;
     f32x16 hv[4];
-    // `feature` is NOT saved (act columns SW_ACT_FEAT.. stay unwritten): feature_linear has no activation, so the weight
-    // gradients on both sides of it follow from G = d pre_hv^T . h7 (swnerf/model.py _unslot_weight_grads)
-    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
+    seg_mfma<4, 9, SEG_BIAS, 8>(hv, k9, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll

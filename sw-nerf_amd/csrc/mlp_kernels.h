@@ -66,20 +66,20 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     } else {
         trunk_pass<false, TRAIN>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb);
     }
-    // view-direction features: gathered like the position ones
+    // views_linears[0] on cat[feature, input_views] with feature_linear folded in (swnerf_common.h SW_CANON_STEPS): one
+    // segment on [h7 | gamma(d)]; the view-direction features are gathered like the position ones.  TRAIN: h7 and its mask
+    // leave as side stores of this segment.
     const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
     f32x16 k9[9];
-    if (TRAIN) seg_mfma<8, 8, SEG_BIAS, TRAIN ? 8 : 0>(out, in, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
-    else seg_mfma<8, 8, SEG_BIAS>(out, in, ws);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = out[n];
+    for (int n = 0; n < 8; ++n) k9[n] = in[n];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const int col = sw_dir_col(a, h, P.Ld);
         k9[8][a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
     }
     f32x16 hv[4];
-    if (TRAIN) seg_mfma<4, 9, SEG_BIAS, TRAIN ? 8 : 0>(hv, k9, ws, 1.f, SideStore{act_row + SW_ACT_FEAT, nullptr, mb});
+    if (TRAIN) seg_mfma<4, 9, SEG_BIAS, TRAIN ? 8 : 0>(hv, k9, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
     else seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
 #pragma unroll
     for (int n = 0; n < 4; ++n)

@@ -80,6 +80,35 @@ __global__ void pack_headbias_kernel(float* dst, const float* b_a, int n_a, cons
     dst[e] = r < n_a ? b_a[r] : ((r - n_a) < n_b ? b_b[r - n_a] : 0.f);
 }
 
+// feature_linear folded into views_linears.0 (swnerf_common.h, SW_CANON_STEPS): fold[u][i] = sum_o Wv[u][o] W_f[o][i] for
+// i < 256, fold[u][256 + c] = Wv[u][256 + c] for the Cdir view-direction columns, and behind the matrix
+// b_vf[u] = sum_o Wv[u][o] b_f[o] + b_v[u].  Double accumulation, one rounding: the folded row is as close to the exact
+// product as a float can be (the two-layer form rounds `feature` AND the second product).  Block u, thread i.
+// Reference: model.py:49-53 (feature_linear -> cat -> views_linears[0], no activation in between).
+__global__ void __launch_bounds__(256) fold_views_kernel(const float* Wv, int ldv, const float* bv, const float* Wf, const float* bf,
+                                                         int Cdir, float* fold) {
+    __shared__ float wrow[256];
+    const int u = blockIdx.x, i = threadIdx.x;
+    wrow[i] = Wv[(size_t)u * ldv + i];
+    __syncthreads();
+    double acc = 0.0;
+    for (int o = 0; o < 256; ++o) acc += (double)wrow[o] * (double)Wf[(size_t)o * 256 + i];
+    float* row = fold + (size_t)u * SW_FOLD_LD;
+    row[i] = (float)acc;
+    if (i < SW_FOLD_LD - 256) row[256 + i] = i < Cdir ? Wv[(size_t)u * ldv + 256 + i] : 0.f;
+    if (i == 0) {
+        double b = (double)bv[u];
+        for (int o = 0; o < 256; ++o) b += (double)wrow[o] * (double)bf[o];
+        fold[(size_t)128 * SW_FOLD_LD + u] = (float)b;
+    }
+}
+
+// views_linears.0 . feature_linear of the net `params` (canonical order) -> fold [SW_FOLD_FLOATS]
+static int fold_views(const float* const* params, int Cdir, float* fold, hipStream_t st) {
+    hipLaunchKernelGGL(fold_views_kernel, dim3(128), dim3(256), 0, st, params[16], 256 + Cdir, params[17], params[18], params[19], Cdir, fold);
+    return sw_check(hipGetLastError(), "pack_net fold launch");
+}
+
 struct Packer {
     hipStream_t st; float* w; float* b; int Lp, Ld, Lt; int rc;
     void seg(const float* W, const float* bias, int out_dim, int in_dim, int NT, int KT, const int* kt, const int* kb) {
@@ -120,6 +149,17 @@ struct Packer {
             b += s.NT * SW_BIAS_TILE_FLOATS;
         }
     }
+    // NT bias tiles of `bias` [out_dim] alone (no weight steps)
+    void btiles(const float* bias, int out_dim, int NT) {
+        if (rc) return;
+        PackSeg s;
+        s.W = bias; s.b = bias; s.out_dim = out_dim; s.in_dim = out_dim; s.NT = NT; s.KT = 0;
+        for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
+        s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
+        hipLaunchKernelGGL(pack_seg_kernel, dim3((NT * SW_BIAS_TILE_FLOATS + 255) / 256), dim3(256), 0, st, s);
+        rc = sw_check(hipGetLastError(), "pack_net launch");
+        b += NT * SW_BIAS_TILE_FLOATS;
+    }
     void headbias(const float* b_a, int n_a, const float* b_b, int n_b) {
         if (rc) return;
         hipLaunchKernelGGL(pack_headbias_kernel, dim3(1), dim3(64), 0, st, b, b_a, n_a, b_b, n_b);
@@ -159,24 +199,22 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     for (int i = 0; i < np; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net: params[%d] is NULL", i);
     const int Cpos = 3 * (1 + 2 * L_pos), Cdir = 3 * (1 + 2 * L_dir), Ctime = 1 + 2 * L_time;
     hipStream_t st = (hipStream_t)stream;
-    const int t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int b8[8];
-    for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
-
     int vt[9], vb[9];
     for (int i = 0; i < 8; ++i) { vt[i] = KT_TRUNK; vb[i] = 32 * i; }
     vt[8] = KT_DIR; vb[8] = 256;
+    // feature_linear folded into views_linears.0: W_vf | Wv[:, 256:] and b_vf, kept at the end of the (last) CANON blob
+    float* fold = packed + (kind == SWNERF_NET_DNERF ? SW_DNERF_A_FLOATS : 0) + SW_CANON_FOLD_OFFSET;
+    int rc = fold_views(params, Cdir, fold, st);
+    if (rc) return rc;
     auto canon = [&](Packer& pk) {
         pk.trunk(params, params[20], params[21], 1, Cpos, 0, params[23], 3);       // ... alpha_linear + head biases
-        pk.seg(params[18], params[19], 256, 256, 8, 8, t8, b8);                    // FEAT
-        pk.seg(params[16], params[17], 128, 256 + Cdir, 4, 9, vt, vb);             // VIEWS
+        pk.seg(fold, fold + 128 * SW_FOLD_LD, 128, SW_FOLD_LD, 4, 9, vt, vb);      // VIEWSF on [h7 | gamma(d)]
         pk.vecs(params[22], 3, 128);                                               // rgb_linear.weight
     };
     auto tail = [&](float* wbase, const float* head) {
         return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
     };
 
-    int rc = 0;
     if (kind == SWNERF_NET_DNERF) {
         Packer pk{st, packed, packed + SW_DNERF_W_FLOATS, L_pos, L_dir, L_time, 0};
         pk.trunk(params + 24, params[40], params[41], 3, Cpos, Ctime);             // deformation net
@@ -194,9 +232,23 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     if ((rc = tail(pk.w, packed))) return rc;
     // the view branch once more, as a stream that wraps onto itself (biases: the tiles packed above)
     Packer vl{st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time, 0};
-    vl.seg(params[16], nullptr, 128, 256 + Cdir, 4, 9, vt, vb);
+    vl.seg(fold, nullptr, 128, SW_FOLD_LD, 4, 9, vt, vb);
     if (vl.rc) return vl.rc;
     return tail(vl.w, packed + SW_CANON_VL_OFFSET);
+}
+
+// The canonical net's bias / head tiles in the UNFOLDED order (SW_X3_CANON_BIAS_TILES): what the bf16x3 core consumes, which
+// still runs feature_linear as its own layer (mlp_core_x3.h).  Called by swnerf_pack_net_x3_kind (x3_kernels.hip).
+int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStream_t st) {
+    Packer pk{st, nullptr, dst, 0, 0, 0, 0};
+    for (int l = 0; l < 8; ++l) pk.btiles(params[2 * l + 1], 256, 8);                  // pts_linears.l.bias
+    pk.vecs(params[20], 1, 256);                                                       // alpha_linear.weight
+    pk.headbias(params[21], 1, params[23], 3);                                         // [b_alpha, b_r, b_g, b_b]
+    pk.btiles(params[19], 256, 8);                                                     // feature_linear.bias
+    pk.btiles(params[17], 128, 4);                                                     // views_linears.0.bias
+    pk.vecs(params[22], 3, 128);                                                       // rgb_linear.weight
+    if (!pk.rc && pk.b != dst + SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_x3: bias layout mismatch");
+    return pk.rc;
 }
 
 // use_viewdirs=False (model.py:59-60): the trunk alone; output_linear's rows ride as bias-style tiles like the other heads.
@@ -254,9 +306,12 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
     const bool ig = bwd_kind == SWNERF_BWD_CANON_INPUT_GRAD || fused;
     const size_t wfloats = fused ? SW_BWD_DN_W_FLOATS : (ig ? SW_BWD_IG_W_FLOATS : SW_BWD_W_FLOATS);
     Packer pk{st, packed_bwd, packed_bwd + wfloats, L_pos, L_dir, 0, 0};
+    // d h7 = W_vf^T . d pre_hv (the fold of swnerf_pack_net, recomputed into this blob's scratch behind the bias tiles)
+    float* fold = packed_bwd + wfloats + (SW_BWD_BIAS_TILES + (fused ? 24 : 0)) * SW_BIAS_TILE_FLOATS;
+    int rcf = fold_views(params, Cdir, fold, st);
+    if (rcf) return rcf;
     pk.segT(params[22], 3, 128, 0, 128, 4, 1);                       // rgb_linear.weight [3,128]^T
-    pk.segT(params[16], 128, 256 + Cdir, 0, 256, 8, 4);              // views_linears.0.weight[:, :256]^T
-    pk.segT(params[18], 256, 256, 0, 256, 8, 8);                     // feature_linear.weight^T
+    pk.segT(fold, 128, SW_FOLD_LD, 0, 256, 8, 4);                    // W_vf^T  (views_linears.0[:, :256] . feature_linear)
     for (int l = 7; l >= 1; --l) {                                   // pts_linears.l.weight[:, -256:]^T
         if (ig && l == 5) pk.segT(params[10], 256, Cpos + 256, 0, Cpos, 2, 8, 1);   // ... [:, :Cpos]^T -> d gamma(x)
         pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);

@@ -44,8 +44,8 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
     ws_start(ws, P.w0, lds_bias, lds_ring, lane);
     trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
     const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
-    seg_mfma<8, 8, SEG_BIAS>(out, in, ws);                   // feature = feature_linear(h)
-    // the ring now holds the first VIEWS steps; the views-loop region starts with the same ones
+    // feature_linear is folded into the view layer (swnerf_common.h SW_CANON_STEPS): the loop below runs on [h7 | gamma(d)].
+    // The ring now holds the first VIEWSF steps; the views-loop region starts with the same ones
     ws.base = reinterpret_cast<const char*>(P.wvl);
     float sr = 0.f, sg = 0.f, sb = 0.f;
     const int64_t nv = P.shared ? P.V : 1;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
         const float* dp = P.dirs + (P.shared ? v : rr) * 3;
         f32x16 k9[9];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) k9[n] = out[n];
+        for (int n = 0; n < 8; ++n) k9[n] = in[n];
         pe_dir(dp[0], dp[1], dp[2], h, k9[8]);
         ws.bias = lds_bias + SW_CANON_BIAS_TILE_VIEWS * SW_BIAS_TILE_FLOATS + h * 16;
         f32x16 hv[4];

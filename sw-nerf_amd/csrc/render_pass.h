@@ -148,7 +148,7 @@ template <bool DNERF, bool TRAIN> struct PassLds {
 // tile + depth slots | per wave: resampling scratch
 // (D-NeRF: both bias-tile sets, and no gamma(d) tile - x3_net_dn evaluates it - so that the resampling scratch still fits)
 template <bool DNERF> struct X3Lds {
-    static constexpr int BIAS = DNERF ? SW_LDS_BIAS_FLOATS : SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    static constexpr int BIAS = (DNERF ? SW_DEFORM_BIAS_TILES + SW_X3_CANON_BIAS_TILES : SW_X3_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS;
     static constexpr int DIR = DNERF ? 0 : 16 * 64;
     static constexpr int WAVE = DIR + SW_ZSLOT_FLOATS;
     static constexpr int FIXED = BIAS + X3_RING_FLOATS + 4 * WAVE;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                 }
             }
             tile_fetch(lds_dir, lane, demb);
-            canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+            canon_tail_train(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if (DNERF && PREC != 0) {
             if constexpr (DNERF && PREC != 0) {
 #pragma nounroll
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             extra = o5[4] + ws.bias[4];
         } else if (TRAIN) {
             // the same tile, and everything the backward needs goes out as side stores of the segments (mlp_core.h
-            // SideStore): gamma(x) with layer 0, h_l and its ReLU mask with layer l+1, feature with the view layer
+            // SideStore): gamma(x) with layer 0, h_l and its ReLU mask with layer l+1 (h7 with the view layer)
             const int64_t prow = (ray * ntiles + tile) * 32 + j;
             float* act_row = P.act + prow * SW_ACT_LD + 4 * h;
             float* mask_tile = P.bits + (ray * ntiles + tile) * SW_MASK_TILE_FLOATS + lane * 4;
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                 *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
             }
             trunk_pass<false, true, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb, xs_row);
-            canon_tail_train(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+            canon_tail_train(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if constexpr (PREC != 0) {
             head[1] = 0.f; head[2] = 0.f;
 #ifdef X3_NO_PIPE                                   // the plain form (split phase between layers): experiments / reference
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         if (!TRAIN && PREC == 0 && VIEWS) {
             f32x16 demb;
             tile_fetch(lds_dir, lane, demb);
-            canon_tail(in, out, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
+            canon_tail(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
         }
         SW_STAMP(pt3);
         if constexpr (PREC == 0) ws_rewind(ws, P.w0, lds_bias, lane);

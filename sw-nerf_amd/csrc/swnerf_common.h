@@ -28,14 +28,24 @@
 // The 1- and 3-output heads (alpha_linear, rgb_linear, _time_out) are NOT in the MFMA stream: a 32-wide
 // padded tile would spend 128 / 64 MFMAs on 1 / 3 useful rows.  They are VALU dot products over the
 // features a lane already holds (mlp_core.h head_valu); their weights sit with the biases in LDS.
-// canonical net stream: L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | FEAT | VIEWS
+// canonical net stream: L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | VIEWSF
+// VIEWSF = feature_linear FOLDED into views_linears.0 (round 4).  feature_linear has no activation (model.py:49-51:
+// feature = feature_linear(h); h = cat[feature, input_views]; views_linears[0](h)), so
+//   pre_hv = Wv[:, :256] (W_f h7 + b_f) + Wv[:, 256:] gamma(d) + b_v  =  W_vf h7 + Wv[:, 256:] gamma(d) + b_vf,
+//   W_vf = Wv[:, :256] . W_f  (128 x 256),   b_vf = Wv[:, :256] . b_f + b_v
+// - ONE 4 x 9 segment on [h7 | gamma(d)] instead of an 8 x 8 and a 4 x 9 one: 8256 MFMAs per tile instead of 9280.  The
+// pack kernel forms W_vf / b_vf with double accumulation and one rounding (pack_kernels.hip fold_views_kernel); module
+// parameters, checkpoints and the weight-gradient algebra (G-based: swnerf_feature_finish) are untouched.
 #define SW_CANON_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
-                        2 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_VIEWS)
+                        2 * SW_STEPS_TRUNK + SW_STEPS_VIEWS)
 // "bias" tiles of 32 floats ([h][r], the accumulator-init layout) in consumption order:
 //   L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8, then 1 tile of head biases (alpha, r, g, b) |
-//   FEAT 8 | VIEWS 4 | rgb_linear.weight 3 x 4
-#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 8 + 4 + 12)
-#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 8 + 1 + 8)   // index of the first views_linears bias tile
+//   VIEWSF 4 (b_vf) | rgb_linear.weight 3 x 4
+#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 4 + 12)
+#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 8 + 1)   // index of the first views_linears bias tile
+// the folded matrix itself rides at the end of a CANON blob: [128][SW_FOLD_LD] = [W_vf | Wv[:, 256:]] then b_vf[128]
+#define SW_FOLD_LD 288
+#define SW_FOLD_FLOATS (128 * SW_FOLD_LD + 128)
 // deformation net stream: D0 | D1..D4 | D5(trunk) D5(emb) | D6 D7 ;  bias tiles: 64 | _time_out.weight 3 x 8 | 1 head-bias tile
 #define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
 #define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 24 + 1)
@@ -49,14 +59,15 @@
 #define SW_NOVIEW_W_FLOATS ((SW_NOVIEW_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_NOVIEW_FLOATS (SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(SW_NOVIEW_MAX_OUT) * SW_BIAS_TILE_FLOATS)
 
-// blob CANON : [canon steps][ring tail = copy of first SW_TAIL steps][canon bias][views loop]
+// blob CANON : [canon steps][ring tail = copy of first SW_TAIL steps][canon bias][views loop][fold scratch]
 // views loop  : [VIEWS steps][tail = copy of the first SW_TAIL VIEWS steps] - the view
 //               branch as a stream that wraps onto itself, for queries of many view directions per
 //               point (swnerf_query_points: trunk and density once, view branch V times)
 #define SW_CANON_W_FLOATS   ((SW_CANON_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_CANON_VL_OFFSET  (SW_CANON_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 #define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_TAIL) * SW_STEP_FLOATS)
-#define SW_CANON_FLOATS     (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
+#define SW_CANON_FOLD_OFFSET (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
+#define SW_CANON_FLOATS     (SW_CANON_FOLD_OFFSET + SW_FOLD_FLOATS)
 // blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
 // (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
 #define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_TAIL) * SW_STEP_FLOATS)
@@ -64,26 +75,27 @@
 #define SW_DNERF_FLOATS     (SW_DNERF_A_FLOATS + SW_CANON_FLOATS)
 
 // ---- training path: per-row activation / gradient buffers [M, SW_ACT_LD], row-major -----------------
-// columns: h_l (post-ReLU) at 256*l for l = 0..7 | feature_linear output at 2048 | views hidden (post-ReLU) at 2304
+// columns: h_l (post-ReLU) at 256*l for l = 0..7 | 2048..2303 unused (feature_linear's output until round 3: it is never
+// formed since the fold above) | views hidden (post-ReLU) at 2304
 #define SW_ACT_LD    2432
-#define SW_ACT_FEAT  2048
 #define SW_ACT_HV    2304
 // backward weight stream (transposed weights, execution order of the dX chain):
-// RGB^T (4x1) | VIEWS^T (8x4) | FEAT^T (8x8) | L7^T .. L1^T (8x8 each); then the alpha_linear weight as 8 bias tiles
-#define SW_BWD_STEPS (16 + 128 + 256 + 7 * 256)
+// RGB^T (4x1) | VIEWSF^T = W_vf^T (8x4) | L7^T .. L1^T (8x8 each); then the alpha_linear weight as 8 bias tiles
+#define SW_BWD_STEPS (16 + 128 + 7 * 256)
 #define SW_BWD_W_FLOATS ((SW_BWD_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_BWD_BIAS_TILES 8
-#define SW_BWD_FLOATS (SW_BWD_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// (each canonical backward blob ends with SW_FOLD_FLOATS of scratch: the folded matrix its VIEWSF^T segment was packed from)
+#define SW_BWD_FLOATS (SW_BWD_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + SW_FOLD_FLOATS)
 // ... with the gradient w.r.t. the embedded positions (D-NeRF training: it flows on into the deformation net):
-// RGB^T | VIEWS^T | FEAT^T | L7^T L6^T | L5[:, :Cpos]^T (2x8) | L5[:, Cpos:]^T | L4^T .. L1^T | L0^T (2x8)
+// RGB^T | VIEWSF^T | L7^T L6^T | L5[:, :Cpos]^T (2x8) | L5[:, Cpos:]^T | L4^T .. L1^T | L0^T (2x8)
 #define SW_BWD_IG_STEPS (SW_BWD_STEPS + 2 * 64)
 #define SW_BWD_IG_W_FLOATS ((SW_BWD_IG_STEPS + SW_TAIL) * SW_STEP_FLOATS)
-#define SW_BWD_IG_FLOATS (SW_BWD_IG_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+#define SW_BWD_IG_FLOATS (SW_BWD_IG_W_FLOATS + SW_BWD_BIAS_TILES * SW_BIAS_TILE_FLOATS + SW_FOLD_FLOATS)
 // fused D-NeRF backward (render_pass_backward_kernel<true>): the input-gradient canonical stream, then the deformation
 // stream, ONE ring; bias tiles: alpha_linear.weight (8) then _time_out.weight rows (24)
 #define SW_BWD_DN_STEPS (SW_BWD_IG_STEPS + 7 * 256)
 #define SW_BWD_DN_W_FLOATS ((SW_BWD_DN_STEPS + SW_TAIL) * SW_STEP_FLOATS)
-#define SW_BWD_DN_FLOATS (SW_BWD_DN_W_FLOATS + (SW_BWD_BIAS_TILES + 24) * SW_BIAS_TILE_FLOATS)
+#define SW_BWD_DN_FLOATS (SW_BWD_DN_W_FLOATS + (SW_BWD_BIAS_TILES + 24) * SW_BIAS_TILE_FLOATS + SW_FOLD_FLOATS)
 // deformation net (`_time`): L7^T .. L1^T (trunk columns); then _time_out.weight [3,256] as 3 x 8 bias tiles
 #define SW_DBWD_STEPS (7 * 256)
 #define SW_DBWD_W_FLOATS ((SW_DBWD_STEPS + SW_TAIL) * SW_STEP_FLOATS)
@@ -102,15 +114,18 @@
 #define SW_X3_TAIL_CHUNKS 8       // the stream ends with a copy of its first chunks (>= ring slots)
 #define SW_X3_CHUNK_FLOATS 4096
 #define SW_X3_W_FLOATS ((SW_X3_CANON_CHUNKS + SW_X3_TAIL_CHUNKS) * SW_X3_CHUNK_FLOATS)
-// blob: [weight stream + tail][the canonical bias tiles, as in the fp32 blob]
-#define SW_X3_FLOATS (SW_X3_W_FLOATS + SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
+// blob: [weight stream + tail][the canonical bias tiles in the UNFOLDED order: the bf16x3 core still runs feature_linear as
+// its layer 8 (mlp_core_x3.h) - L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8 + 1 head-bias tile | FEAT 8 | VIEWS 4 |
+// rgb_linear.weight 12; written by sw_pack_canon_bias_unfolded (pack_kernels.hip)]
+#define SW_X3_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 8 + 4 + 12)
+#define SW_X3_FLOATS (SW_X3_W_FLOATS + SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
 // D-NeRF: deformation net groups D0 8x6 (gamma(x) then gamma(t)) | D1..D4 | D5 8x20 | D6 D7, then the canonical groups
 #define SW_X3_DEFORM_GROUPS (48 + 4 * 128 + 160 + 2 * 128)
 #define SW_X3_DEFORM_CHUNKS (SW_X3_DEFORM_GROUPS / 8)
 #define SW_X3_DNERF_W_FLOATS ((SW_X3_DEFORM_CHUNKS + SW_X3_CANON_CHUNKS + SW_X3_TAIL_CHUNKS) * SW_X3_CHUNK_FLOATS)
 // blob DNERF: [deform + canon stream + tail][deform bias][canon bias] then a full CANON x3 blob (the t == 0 branch)
-#define SW_X3_DNERF_A_FLOATS (SW_X3_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
+#define SW_X3_DNERF_A_FLOATS (SW_X3_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_X3_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
 #define SW_X3_DNERF_FLOATS (SW_X3_DNERF_A_FLOATS + SW_X3_FLOATS)
 
 // C/D register r of lane half h of v_mfma_f32_32x32x2_f32 holds row sw_frow(r,h) of the 32x32 tile

@@ -74,11 +74,10 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_dx_kernel(DxDev P) {
     seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
     mask_apply<4>(mask_take(mr), dhv);
     mask_fetch(mr, 7);
-    // d feature = views_linears.0.weight[:, :256]^T . d hv            (no activation on feature_linear)
+    // d h7 = W_vf^T . d pre_hv + alpha_linear.weight * d sigma  (W_vf = views_linears.0.weight[:, :256] . feature_linear.weight:
+    // no activation on feature_linear, so the two transposed layers are one, swnerf_common.h SW_BWD_STEPS), masked by h7 > 0 below
     f32x16 in[8], out[8];
-    seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
-    // d h7 = feature_linear.weight^T . d feature + alpha_linear.weight * d sigma, masked by h7 > 0
-    seg_mfma<8, 8, SEG_BIAS_SCALED, 8>(out, in, ws, dr[3], SideStore{grad_row + SW_ACT_FEAT, nullptr, nomask});
+    seg_mfma<8, 4, SEG_BIAS_SCALED, 4>(out, dhv, ws, dr[3], SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
 #pragma nounroll
     for (int l = 7; l >= 1; --l) {
         // out = d h_l;  d pre_l = out . [h_l > 0];  d h_{l-1} = W_l[:, -256:]^T . d pre_l
@@ -403,8 +402,8 @@ __global__ void __launch_bounds__(256, 1) render_pass_backward_kernel(PassBwdDev
         seg_mfma<4, 1, SEG_ZERO>(dhv, k1, ws);
         mask_apply<4>(mask_take(mr), dhv);
         mask_fetch(mr, 7);
-        seg_mfma<8, 4, SEG_ZERO, 4>(in, dhv, ws, 1.f, SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
-        seg_mfma<8, 8, SEG_BIAS_SCALED>(out, in, ws, dr[3]);    // d feature is not written out: nothing reads it (model.py _unslot_weight_grads)
+        // d h7 = W_vf^T . d pre_hv + alpha_linear.weight * d sigma: feature_linear folded into the view layer (SW_BWD_STEPS)
+        seg_mfma<8, 4, SEG_BIAS_SCALED, 4>(out, dhv, ws, dr[3], SideStore{grad_row + SW_ACT_HV, nullptr, nomask});
         }
 #pragma nounroll
         for (int l = 7; l >= 1; --l) {

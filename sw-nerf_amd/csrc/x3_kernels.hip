@@ -17,6 +17,8 @@
 
 enum { XK_TRUNK = 0, XK_POS0 = 1, XK_POS1 = 2, XK_DIR = 3, XK_TIME = 4 };
 
+int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStream_t st);   // pack_kernels.hip
+
 struct X3Seg {
     const float* W; int out_dim, in_dim, NT, KB;
     int ktype[20], kbase[20];       // per k-block: slot map and the first weight column of its tile
@@ -121,8 +123,10 @@ extern "C" int swnerf_pack_net_x3_kind(int kind, const float* const* params, int
         if (pk.w != reinterpret_cast<unsigned*>(packed_x3) + (size_t)(SW_X3_DEFORM_CHUNKS + SW_X3_CANON_CHUNKS) * SW_X3_CHUNK_FLOATS)
             return sw_fail(SWNERF_E_ARG, "pack_net_x3: internal layout mismatch");
         if ((rc = copy(reinterpret_cast<float*>(pk.w), packed_x3, (size_t)SW_X3_TAIL_CHUNKS * SW_X3_CHUNK_FLOATS, "pack_net_x3 tail copy"))) return rc;
+        // bias tiles: the deformation net's as in the fp32 blob, the canonical net's in the unfolded order (this core runs feature_linear)
         if ((rc = copy(packed_x3 + SW_X3_DNERF_W_FLOATS, packed_fp32 + SW_DNERF_W_FLOATS,
-                       (size_t)(SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS, "pack_net_x3 bias copy"))) return rc;
+                       (size_t)SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, "pack_net_x3 bias copy"))) return rc;
+        if ((rc = sw_pack_canon_bias_unfolded(params, packed_x3 + SW_X3_DNERF_W_FLOATS + SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, st))) return rc;
         packed_x3 += SW_X3_DNERF_A_FLOATS;                                          // then the canon-only blob (t == 0 branch)
         packed_fp32 += SW_DNERF_A_FLOATS;
     }
@@ -132,7 +136,7 @@ extern "C" int swnerf_pack_net_x3_kind(int kind, const float* const* params, int
     if (pk.w != reinterpret_cast<unsigned*>(packed_x3) + (size_t)SW_X3_CANON_CHUNKS * SW_X3_CHUNK_FLOATS)
         return sw_fail(SWNERF_E_ARG, "pack_net_x3: internal layout mismatch");
     if ((rc = copy(reinterpret_cast<float*>(pk.w), packed_x3, (size_t)SW_X3_TAIL_CHUNKS * SW_X3_CHUNK_FLOATS, "pack_net_x3 tail copy"))) return rc;
-    return copy(packed_x3 + SW_X3_W_FLOATS, packed_fp32 + SW_CANON_W_FLOATS, (size_t)SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS, "pack_net_x3 bias copy");
+    return sw_pack_canon_bias_unfolded(params, packed_x3 + SW_X3_W_FLOATS, st);
 }
 
 extern "C" int swnerf_pack_net_x3(const float* const* params, int L_pos, int L_dir, const float* packed_canon, float* packed_x3, void* stream) {
@@ -154,9 +158,9 @@ extern "C" int swnerf_render_pass_x3(const swnerf_pass_args* args, int terms, vo
     const bool dn = a.kind == SWNERF_NET_DNERF;
     PassDev P = {};
     P.a = a;
-    P.nbias = SW_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
+    P.nbias = SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS;
     if (!dn) { P.w0 = a.packed; P.b0 = a.packed + SW_X3_W_FLOATS; }
-    else if (a.run_deform) { P.w0 = a.packed; P.b0 = a.packed + SW_X3_DNERF_W_FLOATS; P.two_pass = 1; P.nbias = SW_LDS_BIAS_FLOATS; }
+    else if (a.run_deform) { P.w0 = a.packed; P.b0 = a.packed + SW_X3_DNERF_W_FLOATS; P.two_pass = 1; P.nbias = (SW_DEFORM_BIAS_TILES + SW_X3_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS; }
     else { const float* c = a.packed + SW_X3_DNERF_A_FLOATS; P.w0 = c; P.b0 = c + SW_X3_W_FLOATS; }
     size_t lds = (size_t)(dn ? X3Lds<true>::FIXED : X3Lds<false>::FIXED) * sizeof(float);
     if (a.n_importance > 0) {

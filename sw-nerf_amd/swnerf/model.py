@@ -181,9 +181,19 @@ def _rgb4_finish(g, rgb4):
 SW_ACT_HV = 2304          # csrc/swnerf_common.h: column of the view hidden layer in the act / grad rows
 
 
-def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g, rgb4=None):
+def _feature_buffers(device):
+    """Zeroed accumulators around feature_linear for the op path: G = d pre_hv^T . h7 [128, 256] and the 4-row form of
+    alpha_linear's gradient (A = d raw [M, 4]; row 3) with its bias - see _feature_finish."""
+    z = torch.zeros(128 * 256 + 4 * 256 + 4, dtype=torch.float32, device=device)
+    return z[:32768].view(128, 256), z[32768:33792].view(4, 256), z[33792:33796]
+
+
+def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g, rgb4, fbufs):
     """dW / db of the 12 Linear layers of the canonical net (g: zeroed fp32 tensors in _CANON_ORDER) from the
-    dX chain's `grad`, the saved `act`, the embedded inputs x = [gamma(x) | gamma(d)] and d raw."""
+    dX chain's `grad`, the saved `act`, the embedded inputs x = [gamma(x) | gamma(d)] and d raw.  feature_linear is folded
+    into the view layer in every kernel (csrc/swnerf_common.h SW_CANON_STEPS), so neither `feature` nor d feature exists:
+    its two neighbours' gradients come from G (fbufs; finished by _feature_finish)."""
+    gfeat, a4w, a4b = fbufs
     mm = lambda A, a_col, No, B, b_col, Ni, wi, c_col, with_bias: _gemm_tn(
         L, st, M, A, a_col, No, B, b_col, Ni, g[wi], c_col, g[wi + 1] if with_bias else None)
     mm(grad, 0, 256, x, 0, Cpos, 0, 0, True)                                   # pts_linears.0
@@ -191,11 +201,23 @@ def _canon_weight_grads(L, st, M, grad, act, x, d_out, Cpos, Cdir, g, rgb4=None)
         mm(grad, 256 * l, 256, act, 256 * (l - 1), 256, 2 * l, 0, True)
     # pts_linears.5 = [pts | h4]: one pass over d pre_5 for both column blocks
     _gemm_tn_fused(L, st, M, grad, 1280, act, 1024, g[10], Cpos, g[11], B2=x, b2_col=0, Ni2=Cpos, C2=g[10], c2_col=0)
-    mm(grad, 2304, 128, act, 2048, 256, 16, 0, True)                           # views_linears.0 = [feature | dirs]
-    mm(grad, 2304, 128, x, Cpos, Cdir, 16, 256, False)
-    # feature_linear, and alpha_linear riding on its pass over h7
-    _gemm_tn_fused(L, st, M, grad, 2048, act, 1792, g[18], 0, g[19], A2=d_out, a2_col=3, No2=1, C3=g[20], bias3=g[21])
+    _gemm_tn(L, st, M, grad, SW_ACT_HV, 128, act, 1792, 256, gfeat, 0, g[17])  # G (+ views_linears.0.bias)
+    mm(grad, SW_ACT_HV, 128, x, Cpos, Cdir, 16, 256, False)                    # views_linears.0, gamma(d) columns
+    _gemm_tn(L, st, M, d_out, 0, 4, act, 1792, 256, a4w, 0, a4b)               # alpha_linear = row 3 of d raw^T . h7
     _rgb_weight_grad(L, st, M, d_out, act, g, rgb4)
+
+
+def _feature_finish(L, st, gfeat, a4w, a4b, g, params):
+    """Everything that hangs on feature_linear, from G = sum_rows d pre_hv (x) h7 (params / g in _CANON_ORDER):
+      feature = W_f h7 + b_f   =>  d views_linears.0.weight[:, :256] = sum d pre_hv (x) feature = G W_f^T + db_hv (x) b_f
+      d feature = Wv_f^T d pre_hv  =>  d feature_linear.weight = sum d feature (x) h7 = Wv_f^T G,  d feature_linear.bias = Wv_f^T db_hv
+    (Wv_f = views_linears.0.weight[:, :256]; three 128 x 256 x 256 products per step instead of 2 KB of stores, 2 KB of loads
+    and 131 kFLOP per row), and alpha_linear from row 3 of the 4-row form.  model.py:49-53."""
+    f32 = lambda p_: p_.detach() if (p_.dtype == torch.float32 and p_.is_contiguous()) else p_.detach().float().contiguous()
+    Wv, W_f, b_f = f32(params[16]), f32(params[18]), f32(params[19])
+    _lib.check(L.swnerf_feature_finish(_lib.ptr(gfeat), _lib.ptr(g[17]), _lib.ptr(Wv), Wv.stride(0), _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w),
+                                       _lib.ptr(a4b), _lib.ptr(g[16]), g[16].stride(0), _lib.ptr(g[18]), _lib.ptr(g[19]), _lib.ptr(g[20]),
+                                       _lib.ptr(g[21]), st), "feature_finish")
 
 
 def _slot_buffers(device):
@@ -313,20 +335,12 @@ def _noview_unslot(L, st, bufs, Lp, g):
 
 def _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g, params):
     """Finish the canonical net's gradients of a fused training pass (params: its tensors in _CANON_ORDER): slot-ordered
-    columns to their reference columns, then everything that hangs on feature_linear from G = sum_rows d pre_hv (x) h7:
-      feature = W_f h7 + b_f   =>  d views_linears.0.weight[:, :256] = sum d pre_hv (x) feature = G W_f^T + db_hv (x) b_f
-      d feature = Wv_f^T d pre_hv  =>  d feature_linear.weight = sum d feature (x) h7 = Wv_f^T G,  d feature_linear.bias = Wv_f^T db_hv
-    (Wv_f = views_linears.0.weight[:, :256]; three 128 x 256 x 256 products per step instead of 2 KB of stores, 2 KB of loads
-    and 131 kFLOP per row), and alpha_linear from the 4-row form."""
+    columns to their reference columns, then everything that hangs on feature_linear (_feature_finish)."""
     c0s, c5s, cvs, gfeat, a4w, a4b = slot_bufs
     for cs, nslots, slot0, W, col0 in ((c0s, 64, 0, g[0], 0), (c5s, 64, 0, g[10], 0), (cvs, 32, 64, g[16], 256)):
         _lib.check(L.swnerf_unslot_grad(_lib.ptr(cs), cs.stride(0), cs.shape[0], slot0, nslots, Lp, Ld, W.data_ptr(), W.stride(0),
                                         col0, st), "unslot_grad")
-    f32 = lambda p_: p_.detach() if (p_.dtype == torch.float32 and p_.is_contiguous()) else p_.detach().float().contiguous()
-    Wv, W_f, b_f = f32(params[16]), f32(params[18]), f32(params[19])
-    _lib.check(L.swnerf_feature_finish(_lib.ptr(gfeat), _lib.ptr(g[17]), _lib.ptr(Wv), Wv.stride(0), _lib.ptr(W_f), _lib.ptr(b_f), _lib.ptr(a4w),
-                                       _lib.ptr(a4b), _lib.ptr(g[16]), g[16].stride(0), _lib.ptr(g[18]), _lib.ptr(g[19]), _lib.ptr(g[20]),
-                                       _lib.ptr(g[21]), st), "feature_finish")
+    _feature_finish(L, st, gfeat, a4w, a4b, g, params)
 
 
 def _deform_slot_buffers(device):
@@ -400,9 +414,10 @@ class _MlpTrain(torch.autograd.Function):
         _lib.check(L.swnerf_mlp_backward_dx(_lib.ptr(module.packed_bwd()), _lib.ptr(bits), _lib.ptr(d_out), M, _lib.ptr(grad), st),
                    "mlp_backward_dx")
         g = _zero_grads(params)                                               # order: _CANON_ORDER
-        rgb4 = _rgb4_buffers(x.device)
-        _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g, rgb4)
+        rgb4, fbufs = _rgb4_buffers(x.device), _feature_buffers(x.device)
+        _canon_weight_grads(L, st, M, grad, act, x, d_out, module.input_ch, module.input_ch_views, g, rgb4, fbufs)
         _rgb4_finish(g, rgb4)
+        _feature_finish(L, st, *fbufs, g, params)
         return (None, None) + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 
@@ -458,9 +473,10 @@ class _DnerfTrain(torch.autograd.Function):
         _lib.check(L.swnerf_mlp_backward_dx_pts(_lib.ptr(occ.packed_bwd(_lib.BWD_CANON_INPUT_GRAD)), _lib.ptr(bits_c), _lib.ptr(d_out),
                                                 _lib.ptr(pts2), M, Lp, _lib.ptr(grad_c), _lib.ptr(d_pts), st), "mlp_backward_dx_pts")
         g = _zero_grads(params)
-        rgb4 = _rgb4_buffers(x.device)
-        _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g, rgb4)      # (fills g[0..23])
+        rgb4, fbufs = _rgb4_buffers(x.device), _feature_buffers(x.device)
+        _canon_weight_grads(L, st, M, grad_c, act_c, x2, d_out, Cpos, Cdir, g, rgb4, fbufs)      # (fills g[0..23])
         _rgb4_finish(g, rgb4)
+        _feature_finish(L, st, *fbufs, g, params)
         g_dx = d_pts if d_dx is None else (d_pts + d_dx.float()).contiguous()
         grad_d = torch.empty_like(act_d)
         _lib.check(L.swnerf_deform_backward_dx(_lib.ptr(module.packed_bwd(_lib.BWD_DEFORM)), _lib.ptr(bits_d), _lib.ptr(g_dx), M,

@@ -51,8 +51,9 @@ def test_pass_args_layout_matches_c(built, tmp_path):
 
 def test_packed_sizes_and_argument_errors_without_gpu(built):
     L = built.lib()
-    canon = (2320 + 16) * 256 + 97 * 32 + (144 + 16) * 256             # stream + tail, bias/head tiles, views loop
-    dnerf = (1952 + 2320 + 16) * 256 + (89 + 97) * 32 + canon
+    fold = 128 * 288 + 128                                             # W_vf | Wv[:, 256:] and b_vf: feature_linear folded into the view layer
+    canon = (2064 + 16) * 256 + 89 * 32 + (144 + 16) * 256 + fold      # stream + tail, bias/head tiles, views loop, fold
+    dnerf = (1952 + 2064 + 16) * 256 + (89 + 89) * 32 + canon
     assert L.swnerf_packed_floats(0) == canon and L.swnerf_packed_floats(1) == dnerf and L.swnerf_packed_floats(7) == 0
     # pure argument validation happens before any device call
     assert L.swnerf_render_pass(None, None) == -1 and b"NULL" in L.swnerf_last_error()
@@ -62,9 +63,9 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     assert L.swnerf_sample_pdf(None, None, 4, 5000, 8, None, None, None, 0, None, None, None) != 0
     assert L.swnerf_pack_net(0, None, 10, 4, 0, None, None) == -1
     # training entry points: stream sizes per kind, bit-mask buffer size, NULL / bad-kind rejection
-    bwd = (2192 + 16) * 256 + 8 * 32
+    bwd = (1936 + 16) * 256 + 8 * 32 + fold                            # RGB^T 16 | W_vf^T 128 | L7^T..L1^T 7 x 256
     assert [L.swnerf_packed_bwd_floats_kind(k) for k in (0, 1, 2, 3, 4)] == [
-        bwd, bwd + 128 * 256, (1792 + 16) * 256 + 24 * 32, (2192 + 128 + 1792 + 16) * 256 + 32 * 32, 0]     # 3: the fused D-NeRF stream
+        bwd, bwd + 128 * 256, (1792 + 16) * 256 + 24 * 32, (1936 + 128 + 1792 + 16) * 256 + 32 * 32 + fold, 0]     # 3: the fused D-NeRF stream
     assert L.swnerf_packed_bwd_floats() == bwd and L.swnerf_act_floats_per_row() == 2432
     assert [L.swnerf_mask_floats(m) for m in (0, 1, 32, 33, 786432)] == [0, 2304, 2304, 4608, 786432 // 32 * 2304]
     assert L.swnerf_pack_net_bwd_kind(5, None, 10, 4, None, None) == -1

@@ -42,15 +42,16 @@ def test_mfma_kernels_isa(asm):
         assert not bad, f"{name}: {len(bad)} uses of in-flight asm-load registers, e.g. {bad[0]}"
         dma = len(re.findall(r"global_load_lds_dwordx4", body))
         seen[name] = (stats, dma)
-        # code is unrolled per segment type: L0(64) trunk(256) skip-emb(64) feat(256) views(144)
-        # (+ the 96-step deformation layer 0 in the D-NeRF instantiations); +8 priming DMAs
-        steps = 64 + 256 + 64 + 256 + 144 + (96 if "kernelILb1" in name else 0)
+        # code is unrolled per segment type: L0(64) trunk(256) skip-emb(64) views(144) - feature_linear is folded into the
+        # view layer at pack time (swnerf_common.h SW_CANON_STEPS: 8256 MFMAs per tile instead of 9280), so NO 256-step
+        # feature body may be left - (+ the 96-step deformation layer 0 in the D-NeRF instantiations); +8 priming DMAs
+        steps = 64 + 256 + 64 + 144 + (96 if "kernelILb1" in name else 0)
         if "query_points" in name:
-            steps = 64 + 256 + 64 + 256 + 144
+            steps = 64 + 256 + 64 + 144
         if "render_pass_kernelILb0ELb0ELi0ELb0EE" in name or "render_pass_kernelILb0ELb1ELi0ELb0EE" in name or "mlp_forward_noview" in name:
             steps = 64 + 256 + 64                  # no view branch (inference, TRAIN): L0 (64), trunk body (256), skip-emb (64)
-        if "mlp_backward_dx" in name:              # RGB^T (16) VIEWS^T (128) FEAT^T (256) + the L7..L1 loop body (256)
-            steps = 16 + 128 + 256 + 256          # <true>: + the gamma(x) columns of pts_linears.5 and .0 (64 each)
+        if "mlp_backward_dx" in name:              # RGB^T (16) W_vf^T (128: view layer and feature_linear as one) + the L7..L1 loop body (256)
+            steps = 16 + 128 + 256                # <true>: + the gamma(x) columns of pts_linears.5 and .0 (64 each)
             if "kernelILb1" in name:
                 steps += 128
         if "deform_forward_train" in name:         # _time.0 (96) + trunk body (256) + skip-emb (64)
@@ -58,7 +59,7 @@ def test_mfma_kernels_isa(asm):
         if "deform_backward_dx" in name:           # the _time.7 .. _time.1 loop body
             steps = 256
         if "render_pass_backward" in name:         # the fused backward: the same chain as mlp_backward_dx<false>, per tile
-            steps = 16 + 128 + 256 + 256
+            steps = 16 + 128 + 256
             if "kernelILi1" in name:               # D-NeRF: + the gamma(x+dx) columns (2 x 64) + the deformation loop body
                 steps += 128 + 256
             if "kernelILi2" in name:               # no view directions: the L7..L1 loop body alone (output_linear^T runs on the VALU)
