@@ -8,6 +8,7 @@
 #include "../../include/swnerf.h"
 #include "swnerf_common.h"
 #include "lds_dma.h"
+#include "wave_dpp.h"
 #include "host_util.h"
 #include <type_traits>
 #include <cstdlib>
@@ -23,18 +24,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   dL/drgb_i = w_i * g_rgb * c_i*(1-c_i)
 // gA folds d(acc_map), the white-background term (rgb_map += 1-acc) and disp = 1/max(1e-10, D/A);
 // gD folds d(depth_map) and disp.  Prefix products and suffix sums run in double like the forward.
+// Both scans run on the DPP path (wave_dpp.h; the kernel is VALU-issue bound).  The suffix sums of pass 2 become PREFIX sums
+// over lanes by handing the samples of a 64-sample chunk to the lanes in REVERSE order (lane L owns sample 64 ch + 63 - L): the
+// loads stay one contiguous 1 KiB / 256 B block per wave instruction.  T and w of pass 1 wait in the wave's 2 x S floats of LDS.
 #define R2B_SMAX 1024
 __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(const float* raw, const float* zv, const float* rd, const float* noise,
                                                               int64_t N, int S, int white, const float* g_rgb, const float* g_disp,
-                                                              const float* g_acc, const float* g_depth, const float* g_w, float* d_raw) {
-    __shared__ float sT[4][R2B_SMAX], sW[4][R2B_SMAX], sG[4][R2B_SMAX];
+                                                              const float* g_acc, const float* g_depth, const float* g_w, float* d_raw, int Sp) {
+    extern __shared__ __attribute__((aligned(16))) float r2b_lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
     if (ray >= N) return;
-    float* T_ = sT[wv]; float* W_ = sW[wv]; float* G_ = sG[wv];
+    float* T_ = r2b_lds + wv * 2 * Sp; float* W_ = T_ + Sp;
     const float dx = rd[ray * 3], dy = rd[ray * 3 + 1], dz = rd[ray * 3 + 2];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
     const float gr = g_rgb ? g_rgb[ray * 3] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float* zr = zv + ray * S;
+    const float4* rr = reinterpret_cast<const float4*>(raw) + ray * S;
+    const float* nr = noise ? noise + ray * S : nullptr;
     // pass 1: forward recompute of T, w; accumulate acc and depth for the disparity term
     double Tc = 1.0;
     float pa = 0.f, pd = 0.f;
@@ -42,26 +49,23 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(const float* raw, 
         const int s = base + lane;
         const bool live = s < S;
         const int sc = live ? s : S - 1;
-        const float z = zv[ray * S + sc];
-        float dist = (s + 1 < S) ? (zv[ray * S + s + 1] - z) : 1e10f;
+        const float z = zr[sc];
+        const float z_edge = (lane == 63 && s + 1 < S) ? zr[s + 1] : 0.f;
+        const float zn = wave_from_above_f32(z, z_edge);          // a cross-lane read: never under a lane-dependent branch
+        float dist = (s + 1 < S) ? (zn - z) : 1e10f;
         dist *= dnorm;
-        float sg = raw[(ray * S + sc) * 4 + 3];
-        if (noise) sg += noise[ray * S + sc];
+        float sg = rr[sc].w;
+        if (nr) sg += nr[sc];
         float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
         if (!live) alpha = 0.f;
-        double ps = (double)(1.f - alpha + 1e-10f);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const double up = __shfl_up(ps, o, 64); if (lane >= o) ps *= up; }
-        double ex = __shfl_up(ps, 1, 64);
-        if (lane == 0) ex = 1.0;
-        const float T = (float)(Tc * ex);
-        Tc *= __shfl(ps, 63, 64);
+        const double ps = wave_incl_prod_f64((double)(1.f - alpha + 1e-10f));
+        const float T = (float)(Tc * wave_from_below_f64(ps, 1.0));
+        Tc *= wave_last_f64(ps);
         const float w = alpha * T;
         if (live) { T_[s] = T; W_[s] = w; }
         pa += w; pd += w * z;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { pa += __shfl_xor(pa, o, 64); pd += __shfl_xor(pd, o, 64); }
+    pa = __shfl(wave_sum_to_last_f32(pa), 63, 64); pd = __shfl(wave_sum_to_last_f32(pd), 63, 64);
     float gA = g_acc ? g_acc[ray] : 0.f, gD = g_depth ? g_depth[ray] : 0.f;
     if (white) gA -= (gr + gg + gb);
     if (g_disp) {
@@ -74,27 +78,26 @@ __global__ void __launch_bounds__(256) raw2outputs_bwd_kernel(const float* raw, 
     double carry = 0.0;
     const int nch = (S + 63) / 64;
     for (int ch = nch - 1; ch >= 0; --ch) {
-        const int s = ch * 64 + lane;
+        const int s = ch * 64 + 63 - lane;               // reversed: lane 0 owns the chunk's last sample
         const bool live = s < S;
         const int sc = live ? s : S - 1;
-        const f32x4 r4 = *reinterpret_cast<const f32x4*>(raw + (ray * S + sc) * 4);
-        const float z = zv[ray * S + sc];
-        const float c0 = 1.f / (1.f + expf(-r4[0])), c1 = 1.f / (1.f + expf(-r4[1])), c2 = 1.f / (1.f + expf(-r4[2]));
+        const float4 r4 = rr[sc];
+        const float z = zr[sc];
+        const float c0 = 1.f / (1.f + expf(-r4.x)), c1 = 1.f / (1.f + expf(-r4.y)), c2 = 1.f / (1.f + expf(-r4.z));
         const float w = live ? W_[sc] : 0.f, T = live ? T_[sc] : 0.f;
         float G = gr * c0 + gg * c1 + gb * c2 + gA + gD * z;
         if (g_w) G += g_w[ray * S + sc];
-        // inclusive suffix sum of G*w over lanes >= this one, in double
-        double v = live ? (double)G * (double)w : 0.0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const double dn = __shfl_down(v, o, 64); if (lane + o < 64) v += dn; }
-        double after = __shfl_down(v, 1, 64);          // sum over lanes > this one in the chunk
-        if (lane == 63) after = 0.0;
-        const double R = carry + after;
-        carry += __shfl(v, 0, 64);
-        float dist = (s + 1 < S) ? (zv[ray * S + s + 1] - z) : 1e10f;
+        // inclusive sum of G*w over the lanes <= this one = the samples >= s of the chunk, in double
+        const double v = live ? (double)G * (double)w : 0.0;
+        const double incl = wave_incl_sum_f64(v);
+        const double R = carry + wave_from_below_f64(incl, 0.0);     // everything strictly behind sample s
+        carry += wave_last_f64(incl);
+        const float z_edge = (lane == 0 && s + 1 < S) ? zr[s + 1] : 0.f;      // sample s+1 sits one lane BELOW
+        const float zn = dpp_f32<SW_DPP_WAVE_SHR1>(z_edge, z);    // (cross-lane: outside the lane-dependent select)
+        float dist = (s + 1 < S) ? (zn - z) : 1e10f;
         dist *= dnorm;
-        float sg = r4[3];
-        if (noise) sg += noise[ray * S + sc];
+        float sg = r4.w;
+        if (nr) sg += nr[sc];
         const float e = expf(-fmaxf(sg, 0.f) * dist);
         const float p = 1.f - (1.f - e) + 1e-10f;
         const float dLda = G * T - (float)(R / (double)p);
@@ -113,8 +116,9 @@ extern "C" int swnerf_raw2outputs_backward(const float* raw, const float* z_vals
     if (S < 2 || S > R2B_SMAX) return sw_fail(SWNERF_E_UNSUPP, "raw2outputs_backward: 2 <= S <= %d (got %d)", R2B_SMAX, S);
     if (N == 0) return 0;
     if (!raw || !z_vals || !rays_d || !d_raw || N < 0) return sw_fail(SWNERF_E_ARG, "raw2outputs_backward: NULL pointer / negative N");
-    hipLaunchKernelGGL(raw2outputs_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, z_vals, rays_d,
-                       noise, N, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw);
+    const int Sp = (S + 63) & ~63;
+    hipLaunchKernelGGL(raw2outputs_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), (size_t)4 * 2 * Sp * sizeof(float), (hipStream_t)stream,
+                       raw, z_vals, rays_d, noise, N, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw, Sp);
     return sw_check(hipGetLastError(), "raw2outputs_backward launch");
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/swnerf.h"
 #include "swnerf_common.h"
 #include "host_util.h"
+#include "resample.h"
 
 static thread_local char g_err[SW_ERRBUF_LEN] = "";
 char* sw_errbuf() { return g_err; }
@@ -80,20 +81,34 @@ extern "C" int swnerf_ndc_rays(int H, int W, double focal, double near, const fl
 }
 
 // ---- ray batch packing (nerf/run.py:137-158, d_nerf/run_dnerf.py:137-160) ----------------------
+// A block packs 256 rays: the 11- / 12-float rows are assembled in LDS and leave as 16-byte stores of the block's
+// contiguous 11 / 12 KiB of the batch (a row-per-thread store pattern writes 11 dwords at a 44-byte stride: every store
+// instruction touches 22 lines for 256 useful bytes).  The last, partial block stores dword-wise.
 __global__ void __launch_bounds__(256) pack_rays_kernel(const float* ro, const float* rd, int64_t n, float near, float far,
                                                         int has_time, float ft, int ndc, float sx, float sy, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2], dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
-    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float v0 = dx / nrm, v1 = dy / nrm, v2 = dz / nrm;     // viewdirs BEFORE the NDC warp
-    if (ndc) ndc_one(sx, sy, 1.f, ox, oy, oz, dx, dy, dz);       // caller hard-wires near=1. (nerf/run.py:149)
+    __shared__ __attribute__((aligned(16))) float rows[256 * 12];
+    const int t = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 256, i = i0 + t;
     const int cols = has_time ? 12 : 11;
-    float* o = out + i * cols;
-    o[0] = ox; o[1] = oy; o[2] = oz; o[3] = dx; o[4] = dy; o[5] = dz; o[6] = near; o[7] = far;
-    int k = 8;
-    if (has_time) o[k++] = ft;
-    o[k] = v0; o[k + 1] = v1; o[k + 2] = v2;
+    if (i < n) {
+        float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2], dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float v0 = dx / nrm, v1 = dy / nrm, v2 = dz / nrm;     // viewdirs BEFORE the NDC warp
+        if (ndc) ndc_one(sx, sy, 1.f, ox, oy, oz, dx, dy, dz);       // caller hard-wires near=1. (nerf/run.py:149)
+        float* o = rows + t * cols;
+        o[0] = ox; o[1] = oy; o[2] = oz; o[3] = dx; o[4] = dy; o[5] = dz; o[6] = near; o[7] = far;
+        int k = 8;
+        if (has_time) o[k++] = ft;
+        o[k] = v0; o[k + 1] = v1; o[k + 2] = v2;
+    }
+    __syncthreads();
+    float* dst = out + i0 * cols;                                     // 256 * cols * 4 bytes per block: 16-byte aligned when `out` is
+    const int live = (int)min((int64_t)256, n - i0) * cols;
+    if (live == 256 * cols && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        for (int q = t; q < 64 * cols; q += 256) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(rows)[q];
+    } else {
+        for (int q = t; q < live; q += 256) dst[q] = rows[q];
+    }
 }
 
 extern "C" int swnerf_pack_ray_batch(const float* rays_o, const float* rays_d, int64_t n, double near, double far,
@@ -108,32 +123,59 @@ extern "C" int swnerf_pack_ray_batch(const float* rays_o, const float* rays_d, i
 }
 
 // ---- Embedder.embed (embedder.py:33-42) --------------------------------------------------------
-// one thread per OUTPUT element so the [M, d(1+2L)] rows are written fully coalesced
-__global__ void __launch_bounds__(256) embed_kernel(const float* x, int64_t total, int d, int C, float* out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int64_t row = e / C;
-    const int col = (int)(e - row * C);
-    const int blk = col / d, c = col - blk * d;
-    const float v = x[row * d + c];
-    float r = v;
-    if (blk > 0) {
-        const int k = (blk - 1) >> 1;
-        r = sw_sin_or_cos(v * (float)(1 << k), (blk - 1) & 1);
+// out[row] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], blocks d wide.  VALU-issue bound, not HBM
+// bound, once the stores are coalesced: what counts is instructions per output float.  A workgroup builds the image of
+// EMB_ROWS output rows in LDS - one job per (row, band, component) evaluates the sine AND the cosine of its argument with one
+// reduction (sw_sincos_pair: the bits of sw_sin_or_cos), one job per (row, component) copies x - and the image, contiguous in
+// the output and 16-byte aligned, leaves as float4 stores.  Job -> (row, slot) by a multiply-shift (q_magic = ceil(2^24 / Q),
+// exact for the jobs of a block - checked on the host for every accepted (d, L); the 64-bit division per element of the round 1-3 kernel cost more than the sin/cos).
+#define EMB_ROWS 64
+__global__ void __launch_bounds__(256) embed_kernel(const float* x, int64_t M, int d, int L, int R, unsigned q_magic, unsigned d_magic, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float emb_img[];           // [rows][C]
+    const int C = d * (1 + 2 * L), Q = d * (1 + L);                             // jobs per row: d copies + d * L (sin, cos) pairs
+    const int64_t row0 = (int64_t)blockIdx.x * R;                             // R <= EMB_ROWS rows per workgroup (fewer for very wide rows: LDS)
+    const int rows = (int)min((int64_t)R, M - row0);
+    const float* xb = x + row0 * d;
+    for (unsigned j = threadIdx.x; j < (unsigned)(rows * Q); j += 256) {
+        const unsigned row = (j * q_magic) >> 24, q = j - row * (unsigned)Q;
+        float* o = emb_img + row * C;
+        if (q < (unsigned)d) {
+            o[q] = xb[row * d + q];
+        } else {
+            const unsigned p = q - d, k = (p * d_magic) >> 24, c = p - k * (unsigned)d;
+            float sv, cv;
+            sw_sincos_pair(xb[row * d + c] * (float)(1 << k), &sv, &cv);    // x * 2^k is exact (embedder.py:29,36)
+            o[d + 2 * k * d + c] = sv;
+            o[d + 2 * k * d + d + c] = cv;
+        }
     }
-    out[e] = r;
+    __syncthreads();
+    float* dst = out + row0 * C;
+    const int total = rows * C;
+    if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (int i = threadIdx.x; i < total / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(emb_img)[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) dst[i] = emb_img[i];
+    }
 }
 
 extern "C" int swnerf_embed(const float* x, int64_t M, int d, int L, float* out, void* stream) {
     if (M == 0 && d > 0 && L >= 0) return 0;
-    if (!x || !out || M < 0 || d <= 0 || L < 0 || L > 24) return sw_fail(SWNERF_E_ARG, "embed: bad arguments (M=%lld d=%d L=%d)", (long long)M, d, L);
-    const int C = d * (1 + 2 * L);
-    const int64_t total = M * C;
-    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total, 256)), dim3(256), 0, (hipStream_t)stream, x, total, d, C, out);
+    if (!x || !out || M < 0 || d <= 0 || d > 16 || L < 0 || L > 24) return sw_fail(SWNERF_E_ARG, "embed: bad arguments (M=%lld d=%d L=%d; d <= 16, L <= 24)", (long long)M, d, L);
+    const int C = d * (1 + 2 * L), Q = d * (1 + L);
+    const unsigned q_magic = ((1u << 24) + Q - 1) / Q, d_magic = ((1u << 24) + d - 1) / d;   // floor(n / Q) = (n * q_magic) >> 24 for n * Q < 2^24
+    int R = EMB_ROWS;
+    while (R > 1 && (size_t)R * C * sizeof(float) > 64 * 1024) R >>= 1;
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(M, R)), dim3(256), (size_t)R * C * sizeof(float), (hipStream_t)stream,
+                       x, M, d, L, R, q_magic, d_magic, out);
     return sw_check(hipGetLastError(), "embed launch");
 }
 
 // ---- raw2outputs (ray.py:155-198): one wave per ray, 64 samples per sweep ------------------------
+// Loads: raw as one float4 per lane (1 KiB per wave instruction), z one dword per lane; the next sample's depth comes from the
+// lane above (DPP), only lane 63 loads it.  The exclusive cumprod runs in double like ATen's CPU cumprod, on the DPP path
+// (wave_dpp.h: this kernel is VALU-issue bound - 3 sigmoids and an exp per sample - so a scan step must not cost eight
+// instructions and two LDS round trips); the transmittance carried from sweep to sweep is wave-uniform.
 __global__ void __launch_bounds__(256) raw2outputs_kernel(const float* raw, const float* zv, const float* rd, const float* noise,
                                                           int64_t N, int S, int white, float* rgb_map, float* disp, float* acc,
                                                           float* weights, float* depth) {
@@ -142,43 +184,40 @@ __global__ void __launch_bounds__(256) raw2outputs_kernel(const float* raw, cons
     if (ray >= N) return;
     const float dx = rd[ray * 3], dy = rd[ray * 3 + 1], dz = rd[ray * 3 + 2];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* zr = zv + ray * S;
+    const float4* rr = reinterpret_cast<const float4*>(raw) + ray * S;
+    const float* nr = noise ? noise + ray * S : nullptr;
+    float* wr = weights ? weights + ray * S : nullptr;
     float pr = 0.f, pg = 0.f, pb = 0.f, pd = 0.f, pa = 0.f;
-    double Tc = 1.0;
+    double Tc = 1.0;                                      // wave-uniform
     for (int base = 0; base < S; base += 64) {
         const int s = base + lane;
         const bool live = s < S;
         const int sc = live ? s : S - 1;
-        const float4 r4 = *reinterpret_cast<const float4*>(raw + (ray * S + sc) * 4);
-        const float z = zv[ray * S + sc];
-        float dist = (s + 1 < S) ? (zv[ray * S + s + 1] - z) : 1e10f;
+        const float4 r4 = rr[sc];
+        const float z = zr[sc];
+        const float z_edge = (lane == 63 && s + 1 < S) ? zr[s + 1] : 0.f;
+        const float zn = wave_from_above_f32(z, z_edge);
+        float dist = (s + 1 < S) ? (zn - z) : 1e10f;
         dist = dist * dnorm;
         float sg = r4.w;
-        if (noise) sg += noise[ray * S + sc];
+        if (nr) sg += nr[sc];
         float alpha = 1.f - expf(-fmaxf(sg, 0.f) * dist);
         if (!live) alpha = 0.f;
-        double ps = (double)(1.f - alpha + 1e-10f);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(ps, o, 64);
-            if (lane >= o) ps *= up;
-        }
-        double ex = __shfl_up(ps, 1, 64);
-        if (lane == 0) ex = 1.0;
+        const double ps = wave_incl_prod_f64((double)(1.f - alpha + 1e-10f));
+        const double ex = wave_from_below_f64(ps, 1.0);
         const float w = alpha * (float)(Tc * ex);
-        Tc *= __shfl(ps, 63, 64);
-        if (live && weights) weights[ray * S + s] = w;
+        Tc *= wave_last_f64(ps);
+        if (live && wr) wr[s] = w;
         pr += w * (1.f / (1.f + expf(-r4.x)));
         pg += w * (1.f / (1.f + expf(-r4.y)));
         pb += w * (1.f / (1.f + expf(-r4.z)));
         pd += w * z;
         pa += w;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        pr += __shfl_xor(pr, o, 64); pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64);
-        pd += __shfl_xor(pd, o, 64); pa += __shfl_xor(pa, o, 64);
-    }
-    if (lane == 0) {
+    pr = wave_sum_to_last_f32(pr); pg = wave_sum_to_last_f32(pg); pb = wave_sum_to_last_f32(pb);
+    pd = wave_sum_to_last_f32(pd); pa = wave_sum_to_last_f32(pa);
+    if (lane == 63) {
         if (rgb_map) {
             const float bg = white ? (1.f - pa) : 0.f;
             rgb_map[ray * 3] = pr + bg; rgb_map[ray * 3 + 1] = pg + bg; rgb_map[ray * 3 + 2] = pb + bg;
@@ -201,80 +240,35 @@ extern "C" int swnerf_raw2outputs(const float* raw, const float* z_vals, const f
 }
 
 // ---- sample_pdf (ray.py:96-153) [+ sort(cat[z_vals, samples]), nerf/run.py:400] -------------------
+// One wave per ray, four rays per workgroup, each wave in its own LDS slice (no block barrier anywhere): the operands are staged
+// into LDS with coalesced loads, then the wave-level routines of resample.h run - the code of the fused render pass, bit for bit.
+// Slice layout (floats): w[nb-1 -> nbp] | bins[nbp] | cdf[nbp] | z[sort_s] | samples[sort_n]   (nbp = nb rounded up to 4)
 #define SP_MAX_BINS 1024
 #define SP_MAX_SORT 2048
-__global__ void __launch_bounds__(64) sample_pdf_kernel(const float* bins, const float* wts, int64_t N, int nb, int ns,
-                                                        const float* u_in, float* samples, const float* zv, int S,
-                                                        float* z_sorted, float* z_std, int sort_n) {
-    __shared__ float cdf[SP_MAX_BINS];
-    __shared__ float srt[SP_MAX_SORT];
-    const int lane = threadIdx.x;
-    const int64_t ray = blockIdx.x;
-    const float* b = bins + ray * nb;
-    const float* w = wts + ray * (nb - 1);
-    const int nw = nb - 1;
-    // sum(weights + 1e-5): accumulated in double and rounded once - the closest any order can get
-    // to ATen's float sum (whose own blocking is machine dependent); see DESIGN.md "conditioning"
-    double dpart = 0.0;
-    for (int i = lane; i < nw; i += 64) dpart += (double)(w[i] + 1e-5f);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 64);
-    const float part = (float)dpart;
-    double carry = 0.0;
-    for (int base = 0; base < nw; base += 64) {
-        const int i = base + lane;
-        double v = (i < nw) ? (double)((w[i] + 1e-5f) / part) : 0.0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(v, o, 64);
-            if (lane >= o) v += up;
-        }
-        if (i < nw) cdf[i + 1] = (float)(carry + v);
-        carry += __shfl(v, 63, 64);
-    }
-    if (lane == 0) cdf[0] = 0.f;
-    __syncthreads();
-    double sm = 0.0;
-    for (int m = lane; m < ns; m += 64) {
-        const float u = u_in ? u_in[ray * ns + m] : sw_linspace(0.f, 1.f, ns, m);
-        int lo = 0, hi = nb;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(0, lo - 1), above = min(nb - 1, lo);
-        const float cb = cdf[below], ca = cdf[above];
-        float den = ca - cb;
-        if (den < 1e-5f) den = 1.f;
-        const float smp = b[below] + (u - cb) / den * (b[above] - b[below]);
-        samples[ray * ns + m] = smp;
-        if (z_sorted) srt[S + m] = smp;
-        sm += (double)smp;
-    }
+__global__ void __launch_bounds__(256) sample_pdf_kernel(const float* bins, const float* wts, int64_t N, int nb, int ns,
+                                                         const float* u_in, float* samples, const float* zv, int S,
+                                                         float* z_sorted, float* z_std, int sort_s, int sort_n, int slice) {
+    extern __shared__ __attribute__((aligned(16))) float sp_lds[];
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= N) return;                                  // wave-uniform
+    const int nbp = (nb + 3) & ~3;
+    float* w = sp_lds + (threadIdx.x >> 6) * slice;
+    float* b = w + nbp;
+    float* cdf = b + nbp;
+    float* z = cdf + nbp;
+    float* smp = z + sort_s;
+    for (int i = lane; i < nb - 1; i += 64) w[i] = wts[ray * (nb - 1) + i];
+    for (int i = lane; i < nb; i += 64) b[i] = bins[ray * nb + i];
+    if (z_sorted) for (int i = lane; i < S; i += 64) z[i] = zv[ray * S + i];
+    wave_lds_sync();
+    const double sm = wave_sample_pdf(w, nb, ArrayBins{b}, u_in ? u_in + ray * ns : nullptr, ns, cdf, smp, lane);
+    for (int m = lane; m < ns; m += 64) samples[ray * ns + m] = smp[m];      // in draw order (ray.py:150-151), before any sort
     if (z_std) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-        const double mean = sm / ns;
-        double var = 0.0;
-        for (int m = lane; m < ns; m += 64) { const double d = (double)samples[ray * ns + m] - mean; var += d * d; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
-        if (lane == 0) z_std[ray] = (float)sqrt(var / ns);
+        const float sd = wave_zstd(sm, smp, ns, lane);
+        if (lane == 0) z_std[ray] = sd;
     }
-    if (!z_sorted) return;
-    for (int i = lane; i < S; i += 64) srt[i] = zv[ray * S + i];
-    for (int i = S + ns + lane; i < sort_n; i += 64) srt[i] = __builtin_inff();
-    __syncthreads();
-    for (int k = 2; k <= sort_n; k <<= 1)
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int idx = lane; idx < (sort_n >> 1); idx += 64) {
-                const int i = 2 * idx - (idx & (jj - 1)), l = i + jj;
-                const float x = srt[i], y = srt[l];
-                if ((x > y) == ((i & k) == 0)) { srt[i] = y; srt[l] = x; }
-            }
-            __syncthreads();
-        }
-    for (int i = lane; i < S + ns; i += 64) z_sorted[ray * (S + ns) + i] = srt[i];
+    if (z_sorted) wave_rank_merge(z, S, sort_s, smp, ns, sort_n, z_sorted + ray * (S + ns), lane);
 }
 
 extern "C" int swnerf_sample_pdf(const float* bins, const float* weights, int64_t N, int nb, int n_samples, const float* u,
@@ -283,14 +277,19 @@ extern "C" int swnerf_sample_pdf(const float* bins, const float* weights, int64_
     if (!bins || !weights || !samples || N < 0 || nb < 2 || n_samples < 1)
         return sw_fail(SWNERF_E_ARG, "sample_pdf: bad arguments (N=%lld nb=%d n_samples=%d)", (long long)N, nb, n_samples);
     if (nb > SP_MAX_BINS) return sw_fail(SWNERF_E_UNSUPP, "sample_pdf: at most %d bins", SP_MAX_BINS);
-    int sort_n = 0;
+    if (n_samples > SP_MAX_SORT) return sw_fail(SWNERF_E_UNSUPP, "sample_pdf: at most %d samples per ray", SP_MAX_SORT);
+    int sort_s = 0, sort_n = 2;
+    while (sort_n < n_samples) sort_n <<= 1;               // the sample buffer doubles as the fallback sort's power-of-two pad
     if (z_sorted) {
         if (!z_vals || S < 1 || S + n_samples > SP_MAX_SORT) return sw_fail(SWNERF_E_UNSUPP, "sample_pdf: sort needs z_vals and S+n_samples <= %d", SP_MAX_SORT);
-        sort_n = 2;
-        while (sort_n < S + n_samples) sort_n <<= 1;
+        sort_s = 2;
+        while (sort_s < S) sort_s <<= 1;
     }
     if (N == 0) return 0;
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, bins, weights, N, nb, n_samples, u,
-                       samples, z_vals, S, z_sorted, z_std, sort_n);
+    const int nbp = (nb + 3) & ~3;
+    const int slice = 3 * nbp + sort_s + sort_n;
+    const size_t lds = (size_t)4 * slice * sizeof(float);  // <= 4 x (3 x 1024 + 2048 + 2048) x 4 B = 112 KiB
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3(nblocks(N, 4)), dim3(256), lds, (hipStream_t)stream, bins, weights, N, nb, n_samples, u,
+                       samples, z_vals, S, z_sorted, z_std, sort_s, sort_n, slice);
     return sw_check(hipGetLastError(), "sample_pdf launch");
 }

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "mlp_kernels.h"
 #include "mlp_core_x3.h"
+#include "resample.h"
 
 #define SW_LDS_SC 256                    // max coarse samples when resampling
 #define SW_LDS_SORT 1024                 // max S + n_importance (padded to a power of two)
@@ -39,33 +40,6 @@ struct PassDev {
     int skew_mode;          // 0 none | 1 per workgroup | 2 per wave
     int skew_unit;          // s_sleep argument of one skew class (units of 64 clocks)
 };
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Ascending in-place sort of buf[0..n) by one wave, ONLY if it is not already sorted (wave-uniform test); n_pow2 =
-// power of two >= n, buf has room for n_pow2 floats (the pad is filled with +inf).  Bitonic network.
-__device__ __forceinline__ void wave_sort_if_unsorted(float* buf, int n, int n_pow2, int lane) {
-    bool sorted = true;
-    for (int m = lane; m + 1 < n; m += 64) sorted = sorted && (buf[m] <= buf[m + 1]);
-    if (__all(sorted)) return;
-    for (int i = n + lane; i < n_pow2; i += 64) buf[i] = __builtin_inff();
-    wave_lds_sync();
-    for (int k = 2; k <= n_pow2; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int idx = lane; idx < (n_pow2 >> 1); idx += 64) {
-                const int i = 2 * idx - (idx & (jj - 1));
-                const int l = i + jj;
-                const float x = buf[i], y = buf[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) { buf[i] = y; buf[l] = x; }
-            }
-            wave_lds_sync();
-        }
-    }
-}
 
 __device__ __forceinline__ float wave32_sum(float v) {   // sum over the 32 lanes of each half
 #pragma unroll
@@ -469,86 +443,15 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
 #endif
     if (!resample || ghost) return;
 
-    // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; then sort (nerf/run.py:396-400)
+    // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; z_std; then sort (nerf/run.py:396-400, 416) as a rank
+    // merge - the wave-level routines of resample.h, shared with the standalone op
     wave_lds_sync();
-    const int nb = S - 1, nw = S - 2, Ni = a.n_importance;
-    double dpart = 0.0;                              // rounded once: see misc_kernels.hip sample_pdf_kernel
-    for (int i = lane; i < nw; i += 64) dpart += (double)(wc[i + 1] + 1e-5f);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 64);
-    const float wsum = (float)dpart;
-    double carry = 0.0;
-    for (int base = 0; base < nw; base += 64) {      // cumsum accumulates in double like ATen's CPU kernel
-        const int i = base + lane;
-        double v = (i < nw) ? (double)((wc[i + 1] + 1e-5f) / wsum) : 0.0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(v, o, 64);
-            if (lane >= o) v += up;
-        }
-        if (i < nw) cdf[i + 1] = (float)(carry + v);
-        carry += __shfl(v, 63, 64);
+    const int Ni = a.n_importance;
+    const double sm = wave_sample_pdf(wc + 1, S - 1, MidBins{zc}, a.u ? a.u + ray * Ni : nullptr, Ni, cdf, srt, lane);
+    if (a.z_std) {
+        const float sd = wave_zstd(sm, srt, Ni, lane);
+        if (lane == 0) a.z_std[ray] = sd;
     }
-    if (lane == 0) cdf[0] = 0.f;
-    wave_lds_sync();
-    double sm = 0.0;
-    for (int m = lane; m < Ni; m += 64) {
-        const float u = a.u ? a.u[ray * Ni + m] : sw_linspace(0.f, 1.f, Ni, m);
-        int lo = 0, hi = nb;                         // searchsorted(cdf, u, right=True)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(0, lo - 1), above = min(nb - 1, lo);
-        const float cb = cdf[below], ca = cdf[above];
-        const float bb = .5f * (zc[below + 1] + zc[below]), ba = .5f * (zc[above + 1] + zc[above]);
-        float den = ca - cb;
-        if (den < 1e-5f) den = 1.f;
-        const float smp = bb + (u - cb) / den * (ba - bb);
-        srt[m] = smp;
-        sm += (double)smp;
-    }
-    wave_lds_sync();
-    if (a.z_std) {                                   // torch.std(z_samples, unbiased=False), nerf/run.py:416
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-        const double mean = sm / Ni;
-        double var = 0.0;
-        for (int m = lane; m < Ni; m += 64) { const double d = (double)srt[m] - mean; var += d * d; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
-        if (lane == 0) a.z_std[ray] = (float)sqrt(var / Ni);
-    }
-    // ---- z_vals = sort(cat[z_vals, z_samples]) (nerf/run.py:400) as a MERGE of two sorted lists.
-    // The coarse depths are sorted by construction (linspace, or jitter inside disjoint strata).  The samples are
-    // sorted when u is (det: linspace; the inverse cdf is monotone) - up to a last-bit inversion where one bin ends
-    // and the next begins, and not at all for random u - so that is CHECKED, and only an unsorted list is sorted
-    // first (bitonic, on the Ni samples alone).  Then each element's slot = its own index + the number of elements
-    // of the other list in front of it (ties: coarse depths first), found by binary search in the wave's LDS
-    // slice: 13 dependent LDS reads per lane instead of the 36 barrier-separated stages of a 256-element bitonic
-    // sort.  Any correct sort yields the same values as torch.sort.
-    // (The coarse list is checked too: it arrives sorted except, in principle, for a last-bit inversion between two
-    // jittered strata, or when a caller hands unsorted z_vals to a resampling pass.)
-    wave_sort_if_unsorted(srt, Ni, P.sort_n, lane);
-    wave_sort_if_unsorted(zc, S, P.sort_s, lane);
-    float* zf = a.z_fine + ray * (S + Ni);
-    for (int i = lane; i < S; i += 64) {             // coarse depth i goes behind the samples strictly below it
-        const float v = zc[i];
-        int lo = 0, hi = Ni;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (srt[mid] < v) lo = mid + 1; else hi = mid;
-        }
-        zf[i + lo] = v;
-    }
-    for (int m = lane; m < Ni; m += 64) {            // sample m goes behind the coarse depths <= it
-        const float v = srt[m];
-        int lo = 0, hi = S;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (zc[mid] <= v) lo = mid + 1; else hi = mid;
-        }
-        zf[m + lo] = v;
-    }
+    wave_rank_merge(zc, S, P.sort_s, srt, Ni, P.sort_n, a.z_fine + ray * (S + Ni), lane);
 }
 

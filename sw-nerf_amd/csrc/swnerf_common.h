@@ -183,6 +183,26 @@ SW_HD float sw_sin_or_cos(float y, int want_cos) {
     return (q & 2) ? -v : v;
 }
 
+// sin(y) AND cos(y) with the arithmetic of sw_sin_or_cos, bit for bit (one argument reduction and one pair of polynomials
+// for both: the standalone Embedder kernel evaluates a band's sine and cosine in the same thread)
+SW_HD void sw_sincos_pair(float y, float* s_out, float* c_out) {
+    const float n = rintf(y * 0.63661977236758134f);
+    float r = fmaf(-n, 1.57079637050628662e+00f, y);
+    r = fmaf(-n, -4.37113882867379223e-08f, r);
+    r = fmaf(-n, -1.71512451306010346e-15f, r);
+    const int q = (int)n;
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const float sv = (q & 1) ? pc : ps, cv = ((q + 1) & 1) ? pc : ps;
+    *s_out = (q & 2) ? -sv : sv;
+    *c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
 // torch.linspace(start, end, steps)[i] in float32 as the ATen CPU kernel computes it:
 // step = (end-start)/(steps-1); i < steps/2 ? fma(step, i, start) : fma(-step, steps-1-i, end)
 SW_HD float sw_linspace(float start, float end, int steps, int i) {
