@@ -19,6 +19,11 @@ Workloads (BASELINE.json configs / SURVEY.md 8d):
      renders them (64+128, two nets) and the step ends with the all-gather of the frame.
   C5 (strong scaling): D-NeRF 400x400 frame (160 000 rays) at t = 0.5, one DirectTemporalNeRF (deformation +
      canonical net per sample, d_nerf/run_dnerf.py:553-566), same sharding.
+  train (weak scaling; NOT the BASELINE metric - it exists so that the data-parallel training collective has a driver-shaped
+     entry): the reference's training step (nerf/run.py:684-708) on the C2 shape - render(4096 rays, 64+128, two nets,
+     perturb=1) -> mse(rgb) + mse(rgb0) -> backward (fused passes) -> Adam; for N > 1 (or --collective always) the gradients
+     live in swnerf.parallel.GradBucket: one in-place RCCL all-reduce per net, issued async from autograd's hooks (the fine
+     net's under the coarse pass's backward), waited for before optimizer.step().
 fp32 end to end (v_mfma_f32_32x32x2_f32).
 
 --collective always: the N = 1 run joins an RCCL process group of one rank as well (init_process_group("nccl"), the
@@ -57,7 +62,7 @@ FLOP_EXEC_TRAIN_DEFORM_PER_ROW = 2 * (497152 + 7 * 65536 + 497152)        # defo
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); only used by --precision bf16x3 lines
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 N_RAND, N_SAMPLES, N_IMPORTANCE = 4096, 64, 128
-DEFAULT_STEPS = {"C2": (50, 5), "C4": (5, 1), "C5": (10, 2)}
+DEFAULT_STEPS = {"C2": (50, 5), "C4": (5, 1), "C5": (10, 2), "train": (20, 3)}
 
 
 def parse_args():
@@ -65,7 +70,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["C2", "C4", "C5"], default="C2")
+    ap.add_argument("--config", choices=["C2", "C4", "C5", "train"], default="C2",
+                    help="C2 (default): the headline; train: the reference's TRAINING step on the C2 shape (not the BASELINE metric)")
     ap.add_argument("--collective", choices=["auto", "always"], default="auto",
                     help="always: also at N = 1 join an RCCL group (world 1) and end every step with the real all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,6 +180,8 @@ def build_scene(cfg, dev, rank):
     embed_fn, input_ch = embedder.get_embedder(10, 3, 0)
     embeddirs_fn, input_ch_views = embedder.get_embedder(4, 3, 0)
     sc = {"sds_np": []}
+    if cfg == "train":
+        cfg = "C2"
     if cfg == "C5":
         embedtime_fn, input_ch_time = embedder.get_embedder(10, 1, 0)
         sd = synth.dnerf_state_dict(synth.NET_DNERF[0], alpha_bias=synth.NET_DNERF[1])
@@ -535,7 +543,8 @@ def worker(args):
         while pending:
             pending.pop(0)[0].wait()
 
-    if cfg == "C2":
+    train = cfg == "train"
+    if cfg in ("C2", "train"):
         o_np, d_np = synth.pick_rays(H, W, K, c2w, N_RAND, seed=2 + rank)
         rays_o, rays_d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
         n_local, rays_per_step, scaling = N_RAND, world * N_RAND, "weak"
@@ -543,6 +552,25 @@ def worker(args):
         def local():                                     # this rank's part of a step: no collective
             rgb, disp, acc, _ = render.render(H, W, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kw)
             return torch.cat([rgb, disp[:, None], acc[:, None]], -1)
+        if train:
+            # the reference's training step; every rank draws its own batch (seed 2 + rank), gradients are averaged
+            nets_t = [kw["network_fn"], kw["network_fine"]]
+            for m in nets_t:
+                m.train()
+            tgt = torch.rand((N_RAND, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(11 + rank))
+            opt = torch.optim.Adam([p_ for m in nets_t for p_ in m.parameters()], lr=5e-4, betas=(0.9, 0.999))
+            bucket = parallel.GradBucket(nets_t, force=collective)
+            kwt = dict(kw, perturb=1.)
+
+            def local():
+                with torch.enable_grad():
+                    rgb, disp, acc, ex = render.render(H, W, K, chunk=1024 * 32, rays=(rays_o, rays_d), **kwt)
+                    loss = torch.mean((rgb - tgt) ** 2) + torch.mean((ex['rgb0'] - tgt) ** 2)
+                    bucket.zero()
+                    loss.backward()
+                bucket.wait()                            # the all-reduces were issued from autograd's hooks; no-op without a group
+                opt.step()
+                return torch.cat([rgb.detach(), disp.detach()[:, None], acc.detach()[:, None]], -1)
     else:
         lo, hi = synth.shard_range(H * W, world, rank)
         n_local, rays_per_step, scaling = hi - lo, H * W, "strong"
@@ -554,7 +582,7 @@ def worker(args):
             return render_range(lo, hi - lo)
 
     def step():
-        return gather(local())
+        return local() if train else gather(local())        # the training step's collective is the gradient all-reduce inside local()
 
     def fence():
         finish()
@@ -570,7 +598,11 @@ def worker(args):
         # (profiles/r03/clock_ramp.md); W = 5 steps of 8 ms do not reliably cover that
         # - WITHOUT the collective: the number of pre-warm renders differs from rank to rank, collectives must not
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < PREWARM_S:
+        if train:                                        # its local() carries the gradient all-reduce: a FIXED number of steps on every rank
+            for _ in range(8):
+                local()
+            torch.cuda.synchronize(dev)
+        while not train and time.perf_counter() - t_pre < PREWARM_S:
             local()
             torch.cuda.synchronize(dev)
         for _ in range(args.warmup):
@@ -587,10 +619,12 @@ def worker(args):
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (rays_per_step, 5) and bool(torch.isfinite(out[:, :3]).all())
+    assert out.shape == ((n_local if train else rays_per_step), 5) and bool(torch.isfinite(out[:, :3]).all())
 
     ms_kernel = [fine_events[i].elapsed_time(fine_events[i + 1]) for i in range(0, len(fine_events), 2)]
     fine_ms = float(np.mean(ms_kernel)) if ms_kernel else float("nan")
+    if train:
+        args.no_cpu_baseline = args.no_extra = True
     fine_flop = n_local * S_FINE * sc["exec_per_fine_row"]              # MFMA FLOPs the launch EXECUTES (feature_linear folded)
     fine_flop_alg = n_local * S_FINE * sc["flop_per_fine_row"]          # ... the reference's algorithm would
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12
@@ -614,25 +648,30 @@ def worker(args):
               "each rank: get_rays on its contiguous row range -> ray batch -> coarse pass -> resample -> fine pass",
         "C5": "C5: D-NeRF (bouncingballs-like) 400x400 full-image render (160000 rays/step over all GPUs) at t=0.5, 64+128, "
               "one DirectTemporalNeRF (deformation + canonical 8x256 net per sample); each rank renders its contiguous row range",
+        "train": "TRAINING step of the reference (nerf/run.py:684-708) on the C2 shape: render(4096 rays/GPU, 64+128, coarse+fine 8x256 "
+                 "nets, perturb=1) -> mse(rgb)+mse(rgb0) -> backward through the fused passes -> Adam; NOT the BASELINE metric",
     }
     result = {
-        "metric": "rays/sec (64+128 samples/ray)", "value": rays_per_step * args.steps / dt, "unit": "rays/s",
+        "metric": "rays/sec (64+128 samples/ray)" + (", training step" if train else ""), "value": rays_per_step * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32" if not x3 else args.precision,
         "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo; not a measurement)" if rehearsal else ""),
-        "config": {"workload": workloads[cfg] + ("; + RCCL all-gather of [rgb,disp,acc]" if collective else ""),
-                   "collective": (f"{dist.get_backend()} all_gather_into_tensor of the [n,5] pixels per step + all_reduce(MAX) of the time, world {world}"
+        "config": {"workload": workloads[cfg] + (("; + RCCL all-reduce of the gradients" if train else "; + RCCL all-gather of [rgb,disp,acc]") if collective else ""),
+                   "collective": ((f"{dist.get_backend()} all_reduce of the gradient buckets ({bucket.nbytes()} B in {len(bucket.items)} in-place buckets, "
+                                   f"async from autograd hooks) per step + all_reduce(MAX) of the time, world {world}" if train else
+                                   f"{dist.get_backend()} all_gather_into_tensor of the [n,5] pixels per step + all_reduce(MAX) of the time, world {world}")
                                   if collective else "none (N = 1)"),
                    "rays_per_step_per_gpu": n_local, "n_samples": N_SAMPLES, "n_importance": N_IMPORTANCE, "clock_prewarm_s": PREWARM_S,
                    "parallelism": f"ray-sharded dp{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)",
+                     "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)" + (", TRAIN forward variant" if train else ""),
                      "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
                      "flop_accounting": "executed: feature_linear (65 536 MACs/row, no activation) is folded into views_linears.0 at pack "
                                         "time, 527 872 MACs/row run (+497 152 for the deformation net); algorithmic_* = the reference's 593 408",
                      "algorithmic_flop_per_launch": fine_flop_alg, "algorithmic_tflops": fine_flop_alg / (fine_ms * 1e-3) / 1e12,
-                     "step_frac": rays_per_step / world * sc["exec_per_ray"] / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                     "step_frac": rays_per_step / world * (S_FINE + N_SAMPLES) * (FLOP_EXEC_TRAIN_PER_ROW if train else sc["exec_per_fine_row"])
+                                  / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
     }
     if x3:
         # the fine pass runs 3 bf16 MFMAs per product: price the matrix work it really does against the dense bf16 peak

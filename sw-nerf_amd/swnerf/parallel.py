@@ -123,15 +123,96 @@ def frame_renderer(H, W, K, c2w, render_kwargs, frame_time=None, chunk=1 << 30, 
     return render_range
 
 
-def allreduce_gradients(modules, group=None, average=True):
+class GradBucket:
+    """Data-parallel training without the gather / scatter of allreduce_gradients: the gradients of each module LIVE in one
+    flat bucket (`p.grad` are views of it), so the collective is ONE in-place all_reduce per module and nothing is copied
+    around it.  The all-reduce of a module is issued - async, on the backend's own stream behind the kernels that produced the
+    gradients - the moment autograd has accumulated its last parameter (post-accumulate hooks): for the reference's step
+    (nerf/run.py:684-708, loss = mse(rgb) + mse(rgb0)) the fine net's 2.4 MB bucket is reduced over xGMI while the coarse
+    pass's backward still runs; wait() blocks only before optimizer.step().
+
+        bucket = GradBucket([coarse, fine])            # once
+        bucket.zero(); loss.backward(); bucket.wait(); optimizer.step()
+
+    A parameter that got no gradient in a step (a D-NeRF batch at frame_time == 0 leaves `_time.*` untouched,
+    model.py:143-145) contributes its zeros: every rank reduces the same element count by construction.  wait() launches the
+    buckets whose hooks never completed.  force: run the collective in a group of one rank too (bench.py --collective always:
+    the code path of an N-GPU job on a one-GPU box).  No process group and no force: the bucket is only a gradient arena."""
+
+    def __init__(self, modules, group=None, average=True, force=False):
+        self.group, self.average, self.force = group, average, force
+        self.items = []                                  # per module: dict(flat, params, seen, work)
+        for m in modules:
+            if m is None:
+                continue
+            params = [p for p in m.parameters() if p.requires_grad]
+            if not params:
+                continue
+            offs, n = [], 0
+            for p in params:
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4            # every view 16-byte aligned
+            flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+            item = {"flat": flat, "params": params, "seen": 0, "work": None, "launched": False}
+            for p, o in zip(params, offs):
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                p.register_post_accumulate_grad_hook(lambda _p, it=item: self._accumulated(it))
+            self.items.append(item)
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (self.force or dist.get_world_size(self.group) > 1)
+
+    def _launch(self, it):
+        it["launched"] = True
+        if self._active():
+            it["work"] = dist.all_reduce(it["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _accumulated(self, it):
+        it["seen"] += 1
+        if it["seen"] == len(it["params"]) and not it["launched"]:
+            self._launch(it)
+
+    def zero(self):
+        """Start of a step (instead of optimizer.zero_grad(): the gradients must stay views of the bucket)."""
+        for it in self.items:
+            it["flat"].zero_()
+            it["seen"], it["work"], it["launched"] = 0, None, False
+            for p in it["params"]:
+                if p.grad is None or p.grad.data_ptr() < it["flat"].data_ptr() or p.grad.data_ptr() >= it["flat"].data_ptr() + it["flat"].numel() * it["flat"].element_size():
+                    raise RuntimeError("swnerf.parallel.GradBucket: a parameter's .grad no longer lives in the bucket "
+                                       "(use bucket.zero() instead of optimizer.zero_grad(set_to_none=True))")
+
+    def wait(self):
+        """End of backward: every bucket reduced (and averaged), safe to read `p.grad` / call optimizer.step()."""
+        for it in self.items:
+            if not it["launched"]:
+                self._launch(it)
+        for it in self.items:
+            if it["work"] is not None:
+                it["work"].wait()
+                it["work"] = None
+                world = dist.get_world_size(self.group)
+                if self.average and world > 1:
+                    it["flat"].div_(world)
+
+    def nbytes(self):
+        return sum(it["flat"].numel() * it["flat"].element_size() for it in self.items)
+
+
+def allreduce_gradients(modules, group=None, average=True, force=False):
     """Data-parallel training over the ray batch (SURVEY.md section 8e "Training"): ONE all-reduce of every
     parameter gradient, flattened into a single bucket (2 x 595 844 floats = 4.77 MB for coarse + fine) -
     a single RCCL call instead of 48 small ones; xGMI rings are per-link bound, so few large messages.
     The bucket is built from a RANK-INVARIANT list - every parameter with requires_grad, zeros where this
     rank produced no gradient (a D-NeRF rank whose batch sits at frame_time == 0 takes the zero_canonical
     branch, model.py:143-145, and leaves `_time.*` without .grad) - so every rank contributes the same element
-    count; a parameter gets a .grad afterwards if ANY rank had one."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    count; a parameter gets a .grad afterwards if ANY rank had one.
+    (GradBucket above is the copy-free form for a training loop that can hand it the modules up front.)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force:
+            raise RuntimeError("swnerf.parallel.allreduce_gradients(force=True) needs an initialised process group")
+        return
+    if dist.get_world_size(group) == 1 and not force:        # force: the collective runs in a group of one rank as well
         return
     params = [p for m in modules if m is not None for p in m.parameters() if p.requires_grad]
     if not params:

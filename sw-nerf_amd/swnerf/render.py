@@ -21,6 +21,8 @@ from .model import vallina_NeRF, NeRFOriginal, DirectTemporalNeRF
 
 DEBUG = False
 PASS_HOOK = None     # bench.py: callable(phase, n_rays, n_samples) with phase in {"begin", "end"} around each launch
+Z_TAP = None         # tools/soak_r04.py: a dict that receives the fine depths a render_rays call drew ("fused" / "unfused") - the static
+#                      reference does not return them, and a soak must attribute a colour difference to a moved depth before it accepts it
 
 
 def batchify(fn, chunk):
@@ -457,6 +459,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     p0 = coarse_pass_resampled(ray_batch, network_fn, N_samples, N_importance, want=want, u=u, lindisp=lindisp, t_rand=t_rand,
                                noise=noise(N_samples), white_bkgd=white_bkgd)
     S1 = N_samples + N_importance
+    if Z_TAP is not None:
+        Z_TAP["fused"] = p0["z_fine"]
     run_fn = network_fn if network_fine is None else network_fine
     p1 = render_pass(ray_batch, run_fn, S1, z_vals=p0["z_fine"], noise=noise(S1), white_bkgd=white_bkgd,
                      want=["rgb_map", "disp_map", "acc_map"] + (["raw"] if retraw else []))
@@ -520,6 +524,8 @@ def _render_rays_unfused(ray_batch, network_fn, network_query_fn, N_samples, ret
         z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
         z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest).detach()
         z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1)
+        if Z_TAP is not None:
+            Z_TAP["unfused"] = z_vals
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
         run_fn = network_fn if network_fine is None else network_fine
         raw = network_query_fn(pts, viewdirs, run_fn)

