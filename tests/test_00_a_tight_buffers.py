@@ -5,8 +5,9 @@ last row leaves the mapping and the process dies with "Memory access fault" inst
 AddressSanitizer is not available on this pool.  Includes the generic path's shapes: W = 256 with view directions and skips
 [2, 5] forward + backward (the 128 x 283 weight gradient that faulted in round 3) and a D != 8 net.
 
-Fresh child processes, started before this pytest process has initialised the GPU (this module sorts first on purpose: a
-process that has may not start programs on this pool).  A few cases per child: a fault costs that child's remaining cases,
+Fresh child processes, started before this pytest process has initialised the GPU (this module sorts FIRST on purpose - in
+front of test_00_bench_launcher.py, whose last test initialises the GPU in-process: a process that has may not start programs
+on this pool).  A few cases per child: a fault costs that child's remaining cases,
 never the suite's process."""
 import os
 import subprocess

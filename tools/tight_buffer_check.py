@@ -5,7 +5,7 @@ gives it a segment of exactly that size, so a kernel that reads or writes one el
 and faults instead of silently touching a neighbour.  (This is how round 3 found the grid-decode bug of the narrow weight-
 gradient GEMM.)  tight_buffer_check.py <case> [<case> ...] runs the cases one after the other in this process (the caching
 allocator is emptied in between, so every case gets fresh exact-size segments); `list` prints the cases.  A GPU memory fault
-aborts the process (exit code 134 / -6): tests/test_00_tight_buffers.py starts it as a child and fails on a non-zero exit OR a
+aborts the process (exit code 134 / -6): tests/test_00_a_tight_buffers.py starts it as a child and fails on a non-zero exit OR a
 "Memory access fault" line in its output.
 Round 4: the generic path's cases - the shape that faulted in round 3 (views_linears.0 of a W = 256 net with view directions
 and skips [2, 5]: a 128 x 283 weight gradient) forward + backward, and a D != 8 net."""
@@ -196,7 +196,7 @@ if case in ("generic_w256_views", "generic_d6"):
     x = tight(torch.randn((M, 90), device=dev))
     out = net(x)
     assert out.shape == (M, 4) and bool(torch.isfinite(out).all())
-    (out * tight(torch.randn((M, 4), device=dev))).sum().backward()
+    (out * torch.randn((M, 4), device=dev)).sum().backward()
     gv = net.views_linears[0].weight.grad
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
     assert float(gv[:, -27:].abs().max()) > 0, "the view-direction columns of views_linears.0 got no gradient (round 3's bug)"
