@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 108
+#define SWNERF_VERSION 109
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -53,7 +53,12 @@ const char* swnerf_last_error(void);
  *   [40,41]  _time_out.{weight,bias}            [3,256]
  * L_pos / L_dir / L_time = number of frequency bands of the embedders
  * (embedder.py:44-59: multires=10 -> C_pos 63, multires_views=4 -> C_dir 27,
- * time multires=10 -> C_time 21).  Limits: L_pos <= 10, L_dir <= 4, L_time <= 10. */
+ * time multires=10 -> C_time 21).  Limits: L_pos <= 10, L_dir <= 4, L_time <= 10.
+ * Since version 109 the pack step FOLDS feature_linear into views_linears.0 (model.py:49-53: feature_linear has no
+ * activation, so views_linears.0(cat[feature_linear(h), dirs]) = [Wv[:, :256] W_f | Wv[:, 256:]] . cat[h, dirs] + (Wv[:, :256] b_f
+ * + b_v); the product is formed in double and rounded once): the kernels run ONE 128 x (256 + C_dir) layer where the
+ * reference runs a 256 x 256 and a 128 x (256 + C_dir) one - 11 % fewer MFMAs per row, same function.  The caller's
+ * tensors, their gradients (swnerf_feature_finish) and checkpoints are untouched. */
 size_t swnerf_packed_floats(int kind);
 int swnerf_pack_net(int kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
                     int L_time, float* packed, void* stream);
@@ -130,7 +135,8 @@ int swnerf_mlp_forward(int kind, const float* packed, const float* x, int64_t M,
 /* ---- training path of the MLP (autograd of model.py:39-62) -----------------
  * forward_train: as swnerf_mlp_forward (SWNERF_NET_CANON) and additionally saves, per row, the
  *   activations the weight-gradient GEMMs need: act [M, swnerf_act_floats_per_row()] row-major
- *   (h_l post-ReLU at column 256*l, l=0..7; feature_linear output at 2048; views hidden at 2304), and the
+ *   (h_l post-ReLU at column 256*l, l=0..7; columns 2048..2303 unused - feature_linear's output is never formed, see
+ *   swnerf_pack_net; views hidden at 2304), and the
  *   ReLU bit masks of every 32-row tile: bits [swnerf_mask_floats(M)] (1 KiB per tile and layer; opaque,
  *   only the backward_dx entry points read it).
  * pack_net_bwd: the transposed weight stream of the dX chain (params as for swnerf_pack_net, first 24).
@@ -336,8 +342,8 @@ int swnerf_render_pass_backward_dnerf(const float* packed_bwd_fused, const float
  * W[o][col0 + column(slot0 + f)] = Cs[o][f] for every real slot f; pad slots are dropped. */
 int swnerf_unslot_grad(const float* Cs, int ld_s, int rows_w, int slot0, int nslots, int L_pos, int L_dir,
                        float* W, int ldw, int col0, void* stream);
-/* The fused training pass stores neither `feature` nor d feature and does not run feature_linear's weight-gradient GEMM
- * (feature_linear has no activation, model.py:50-51).  From G [128,256] = sum_rows d pre_hv (x) h7 (swnerf_gemm_tn of the
+/* No training pass (fused or op by op) stores `feature` or d feature or runs feature_linear's weight-gradient GEMM
+ * (feature_linear has no activation, model.py:50-51; the forward and dX kernels run it folded into the view layer).  From G [128,256] = sum_rows d pre_hv (x) h7 (swnerf_gemm_tn of the
  * gradient rows' view-hidden columns against h7), db_hv [128] (its bias output) and the CURRENT weights this adds
  *   dWv[u][o] += sum_i G[u][i] W_f[o][i] + db_hv[u] b_f[o]      (d views_linears.0.weight[:, :256]; Wv/dWv: [128, ld >= 256])
  *   dW_f[o][i] += sum_u Wv[u][o] G[u][i],   db_f[o] += sum_u Wv[u][o] db_hv[u]      (d feature_linear.weight / .bias)

@@ -20,7 +20,7 @@ if what == "north_star":
     embeddirs_fn, in_views = embedder.get_embedder(4, 3, 0)
     specs = [(synth.nerf_state_dict(s, alpha_bias=ab), dict(input_ch_views=in_views, use_viewdirs=True)) for s, ab in (synth.NET_COARSE, synth.NET_FINE)]
     H = W = 400
-    N, flop_row, use_views = 1024, 2 * 593408, True
+    N, flop_row, use_views = 1024, 2 * (593408 - 65536), True       # EXECUTED MACs: feature_linear is folded into the view layer
 else:
     embeddirs_fn = None
     specs = [(synth.noview_state_dict(s, alpha_bias=ab), dict(input_ch_views=0, use_viewdirs=False)) for s, ab in ((20250321, 0.5), (20250322, 0.7))]
@@ -47,5 +47,5 @@ with torch.no_grad():
         render.render(H, W, K, rays=rays, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-print(f"{what}: {N} rays x (64+128): {dt * 1e3:.3f} ms per render() = {N / dt:,.0f} rays/s = {N * 256 * flop_row / dt / 157.3e12:.4f} of 157.3 TFLOP/s "
+print(f"{what}: {N} rays x (64+128): {dt * 1e3:.3f} ms per render() = {N / dt:,.0f} rays/s = {N * 256 * flop_row / dt / 157.3e12:.4f} of 157.3 TFLOP/s on executed FLOPs "
       f"(wall clock incl. Python, {reps} reps; under a profiler the kernels are serialised with extra gaps)")
