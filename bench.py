@@ -723,6 +723,14 @@ def worker(args):
                                    "(3 x forward for training) / time; psnr_vs_cpu_render_db = the "
                                    "HIP render against the CPU oracle's render of the first psnr_rays rays of that config",
                            "configs": extra_configs(dev)}
+        # the HBM / VALU-issue bound satellites of the path (get_rays, ray-batch pack, Embedder, raw2outputs forward and
+        # backward, sample_pdf + sort as standalone ops), at sizes where they are not launch bound: us, algorithmic bytes, GB/s,
+        # fraction of the 8 TB/s spec and of the 6.29 TB/s a float4 copy reaches (tools/bench_satellites.py; PMC evidence of the
+        # same launches: profiles/r04/satellites*.md)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_satellites
+        torch.cuda.empty_cache()
+        result["extra"]["satellites"] = bench_satellites.run_satellites(dev, reps=10, quiet=True)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if collective:

@@ -23,17 +23,15 @@ for p in (os.path.join(ROOT, "sw-nerf_amd"), ROOT):
 HBM_SPEC, HBM_ACHIEVABLE = 8.0e12, 6.29e12
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--json", default=None)
-    ap.add_argument("--only", default=None)
-    ap.add_argument("--reps", type=int, default=20)
-    args = ap.parse_args()
+def run_satellites(dev, reps=20, only=None, quiet=False):
+    """-> rows (dicts: name, kernel, bound, us, algorithmic_bytes, GBps, frac_of_8TBps, frac_of_achievable_6p29).  bench.py puts
+    them into its record (extra.satellites)."""
+    import types
+    args = types.SimpleNamespace(reps=reps, only=only)
     import numpy as np
     import torch
     from swnerf import _lib, synth
     L = _lib.lib()
-    dev = torch.device("cuda:0")
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = _lib.ptr
     g = torch.Generator(device=dev)
@@ -41,7 +39,12 @@ def main():
     rnd = lambda *s: torch.rand(s, device=dev, generator=g)
     rows = []
 
-    def run(name, kernel, fn, nbytes, note=""):
+    VALU = ("valu", "VALU-issue bound, not HBM bound: the vector ALUs are saturated (profiles/r04/satellites_pmc.md: VALUBusy >= 100 %, "
+                    "counter bytes == algorithmic bytes) - exact expf / IEEE division / double-precision scans per sample")
+    EMB = ("valu", "VALU-issue bound (VALUBusy 52-79 %, profiles/r04/satellites_pmc.md): a sin/cos pair per two output floats")
+
+    def run(name, kernel, fn, nbytes, bound=("hbm", "")):
+        note = bound[1]
         if args.only and args.only not in name:
             return
         for _ in range(3):
@@ -55,10 +58,11 @@ def main():
         torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         bw = nbytes / (us * 1e-6)
-        rows.append({"name": name, "kernel": kernel, "bound": "hbm", "us": us, "algorithmic_bytes": nbytes, "GBps": bw / 1e9,
+        rows.append({"name": name, "kernel": kernel, "bound": bound[0], "us": us, "algorithmic_bytes": nbytes, "GBps": bw / 1e9,
                      "frac_of_8TBps": bw / HBM_SPEC, "frac_of_achievable_6p29": bw / HBM_ACHIEVABLE, "note": note})
-        print(f"{name:64s} {us:9.1f} us  {nbytes / 1e6:9.1f} MB  {bw / 1e9:8.1f} GB/s  {bw / HBM_SPEC:6.1%} of spec  {bw / HBM_ACHIEVABLE:6.1%} of achievable",
-              flush=True)
+        if not quiet:
+            print(f"{name:64s} {us:9.1f} us  {nbytes / 1e6:9.1f} MB  {bw / 1e9:8.1f} GB/s  {bw / HBM_SPEC:6.1%} of spec  {bw / HBM_ACHIEVABLE:6.1%} of achievable",
+                  flush=True)
 
     # ---- get_rays (a1): 800x800 as C4 renders it, and a 4000x4000 grid where launch ramp no longer shows
     K, c2w = synth.lego_camera(800, 800)
@@ -86,7 +90,7 @@ def main():
         x = rnd(M, d) * 12 - 6
         C = d * (1 + 2 * Lb)
         out = torch.empty((M, C), device=dev)
-        run(f"embed {M} x {d} -> {C} (L={Lb})", "embed_kernel", lambda: _lib.check(L.swnerf_embed(p(x), M, d, Lb, p(out), st()), "embed"), M * 4 * (d + C))
+        run(f"embed {M} x {d} -> {C} (L={Lb})", "embed_kernel", lambda: _lib.check(L.swnerf_embed(p(x), M, d, Lb, p(out), st()), "embed"), M * 4 * (d + C), EMB)
     # ---- raw2outputs (a10) forward / backward on the 800x800 frame at S = 192 (and S = 64)
     for S in (192, 64):
         N = 640000
@@ -97,15 +101,15 @@ def main():
                                 torch.empty(N, device=dev), torch.empty((N, S), device=dev))
         run(f"raw2outputs {N} x {S} (all five outputs)", "raw2outputs_kernel",
             lambda: _lib.check(L.swnerf_raw2outputs(p(raw), p(z), p(rd), None, N, S, 1, p(o3), p(o1a), p(o1b), p(w), p(o1c), st()), "r2o"),
-            N * (S * 24 + 12 + 24))
+            N * (S * 24 + 12 + 24), VALU)
         run(f"raw2outputs {N} x {S} (maps only, no weights)", "raw2outputs_kernel",
             lambda: _lib.check(L.swnerf_raw2outputs(p(raw), p(z), p(rd), None, N, S, 1, p(o3), p(o1a), p(o1b), None, p(o1c), st()), "r2o"),
-            N * (S * 20 + 12 + 24))
+            N * (S * 20 + 12 + 24), VALU)
         g3, g1 = rnd(N, 3), rnd(N)
         d_raw = torch.empty_like(raw)
         run(f"raw2outputs backward {N} x {S} (d rgb, d disp, d acc -> d raw)", "raw2outputs_bwd_kernel",
             lambda: _lib.check(L.swnerf_raw2outputs_backward(p(raw), p(z), p(rd), None, N, S, 1, p(g3), p(g1), p(g1), None, None, p(d_raw), st()), "r2ob"),
-            N * (S * 20 + S * 16 + 12 + 20))
+            N * (S * 20 + S * 16 + 12 + 20), VALU)
         del raw, z, w, d_raw
     # ---- sample_pdf + sort (a11): 63 bins -> 128 samples -> 192 sorted depths, the frame's rays
     N, S, Ni = 640000, 64, 128
@@ -115,14 +119,25 @@ def main():
     smp, zs, zstd = torch.empty((N, Ni), device=dev), torch.empty((N, S + Ni), device=dev), torch.empty(N, device=dev)
     run(f"sample_pdf {N} x ({S - 1} bins -> {Ni}), det", "sample_pdf_kernel",
         lambda: _lib.check(L.swnerf_sample_pdf(p(bins), p(wts), N, S - 1, Ni, None, p(smp), None, 0, None, None, st()), "spdf"),
-        N * 4 * ((S - 1) + (S - 2) + Ni))
+        N * 4 * ((S - 1) + (S - 2) + Ni), VALU)
     run(f"sample_pdf + sort {N} x ({S - 1} bins -> {Ni} -> {S + Ni}), det, z_std", "sample_pdf_kernel",
         lambda: _lib.check(L.swnerf_sample_pdf(p(bins), p(wts), N, S - 1, Ni, None, p(smp), p(zc), S, p(zs), p(zstd), st()), "spdf"),
-        N * 4 * ((S - 1) + (S - 2) + S + Ni + (S + Ni) + 1))
+        N * 4 * ((S - 1) + (S - 2) + S + Ni + (S + Ni) + 1), VALU)
     u = rnd(N, Ni)
     run(f"sample_pdf + sort {N} x ({S - 1} bins -> {Ni} -> {S + Ni}), random u", "sample_pdf_kernel",
         lambda: _lib.check(L.swnerf_sample_pdf(p(bins), p(wts), N, S - 1, Ni, p(u), p(smp), p(zc), S, p(zs), p(zstd), st()), "spdf"),
-        N * 4 * ((S - 1) + (S - 2) + S + Ni + Ni + (S + Ni) + 1))
+        N * 4 * ((S - 1) + (S - 2) + S + Ni + Ni + (S + Ni) + 1), VALU)
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    rows = run_satellites(torch.device("cuda:0"), args.reps, args.only)
     if args.json:
         json.dump({"hbm_spec_Bps": HBM_SPEC, "hbm_achievable_Bps": HBM_ACHIEVABLE, "reps": args.reps, "rows": rows}, open(args.json, "w"), indent=1)
 

@@ -63,6 +63,6 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 t = np.mean(np.array(timers), 0)
-flop = N * 256 * 2 * 593408 * 3          # forward + dX + dW (dX skips layer 0 and the view inputs: slightly less)
+flop = N * 256 * 2 * (527872 + 495616 + 527872)   # EXECUTED: forward + dX chain + dW, feature_linear folded (bench.py FLOP_EXEC_TRAIN_PER_ROW)
 print(f"| training step, {N} rays x (64+128), two nets, fp32 | {dt*1e3:.1f} ms/step | {N/dt:,.0f} rays/s | forward {t[0]:.1f} ms, backward {t[1]:.1f} ms, Adam {t[2]:.1f} ms | ~{flop/dt/1e12:.0f} TFLOP/s |")
 print(f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")

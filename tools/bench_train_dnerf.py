@@ -16,7 +16,7 @@ import torch
 from swnerf import synth, runner, render_dnerf
 
 dev = torch.device("cuda:0")
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
 args = SimpleNamespace(expname="bench", basedir="/tmp/swnerf_bench", netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
                        lrate=5e-4, netchunk=1024 * 64, no_reload=True, ft_path=None, N_samples=64, N_importance=128, perturb=1.,
                        use_viewdirs=True, i_embed=0, multires=10, multires_views=4, raw_noise_std=0., dataset_type="blender",
@@ -55,7 +55,7 @@ def step(tv, timers=None):
 
 print("| D-NeRF training step (t = 0.5), fp32, 1x MI355X | ms/step | rays/s | forward / backward / Adam ms |")
 print("|---|---|---|---|")
-for tv in (False, True):
+for tv in ((False,) if "notv" in sys.argv else (False, True)):      # `notv`: the image-loss step alone (for rocprofv3 timelines)
     for _ in range(2):
         step(tv)
     torch.cuda.synchronize()

@@ -1,0 +1,29 @@
+#!/bin/bash
+# trace_timeline.sh <tag> <python tool + args...>: kernel timeline of the LAST complete step of a training tool under
+# rocprofv3 --kernel-trace: start / end / stream of every kernel >= 20 us relative to the step's first forward launch
+# (a step = from one coarse forward render_pass launch to the next one) -> gpurun_out/timeline/<tag>.md
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/timeline; mkdir -p $OUT; rm -rf $OUT/trace_$tag; cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$tag -- python3 "$@" > $OUT/$tag.log 2>&1 || { echo "trace failed"; tail -5 $OUT/$tag.log; exit 1; }
+f=$(find $OUT/trace_$tag -name '*kernel_trace.csv' | head -1)
+python3 - "$f" "${FWD_PER_STEP:-2}" > $OUT/$tag.md <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+per = int(sys.argv[2])
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+fw = [i for i, r in enumerate(rows) if "render_pass_kernel" in r["Kernel_Name"]]
+i0, i1 = fw[-2 * per], fw[-per]
+t0 = int(rows[i0]["Start_Timestamp"])
+print("| start us | end us | dur us | queue | kernel |")
+print("|---|---|---|---|---|")
+busy = 0
+for r in rows[i0:i1]:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    if e - s >= 20000:
+        print(f"| {s / 1e3:.0f} | {e / 1e3:.0f} | {(e - s) / 1e3:.0f} | {r.get('Queue_Id', '?')} | {r['Kernel_Name'].split('(')[0][-60:]} |")
+print(f"\nstep = {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.0f} us from first forward launch to the next step's")
+PY
+grep -i "step" $OUT/$tag.log | grep -v rocprof | tail -3 >> $OUT/$tag.md
+rm -rf $OUT/trace_$tag
+cat $OUT/$tag.md
