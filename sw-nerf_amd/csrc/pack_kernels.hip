@@ -18,24 +18,46 @@
 
 enum { KT_TRUNK = 0, KT_POS0 = 1, KT_POS1 = 2, KT_DIR = 3, KT_TIME = 4 };
 
+// One segment of a pack plan (kept small: a plan of up to PACK_MAX_SEGS of them travels as a kernel argument).
 struct PackSeg {
     const float* W; const float* b;     // b == NULL: accumulate segment, no bias tile
-    int out_dim, in_dim, NT, KT;
-    int ktype[10], kbase[10];
-    int Lp, Ld, Lt;
     float* dstW; float* dstB;
+    int out_dim, in_dim;
+    short NT, KT;
     // transpose != 0 (backward stream): the GEMM's output rows are W's COLUMNS row0.. (out_dim of them) and
     // its k index runs over W's ROWS (kvalid of them): value = W[kbase + col][row0 + row]
-    int transpose, row0, kvalid;
     // rowmap != 0 (transposed only): output row (n, i) is the position-embedding SLOT the lane holding it
     // filled in the forward pass - W column row0 + sw_pos_col(16n + r, h) with frow(r,h) == i - so the dX chain
     // leaves d gamma(x) in the registers pe_pos() wrote gamma(x) to.
-    int rowmap;
+    short transpose, rowmap;
+    int row0, kvalid;
+    int max_steps;                       // > 0: only the first max_steps steps (the ring tail: a copy of a stream's head)
+    // kind 1: a head-bias tile instead - dstB[h][r] = (W ++ b)[r] for r < out_dim + in_dim (W: out_dim floats, b: in_dim floats)
+    short kind;
+    unsigned char ktype[10];
+    short kbase[10];
 };
 
-__global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
-    const int nsteps = s.NT * s.KT * 4;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// A whole net's segments in ONE launch (round 4).  A repack used to be ~16 tiny launches per stream; a training step repacks the
+// forward and the backward stream of both nets after every optimizer step - ~60 launches of a few microseconds each, most of
+// the step's "launch gaps" (profiles/r04/train_step_timeline.md).  first_block: prefix sums of the segments' 256-thread blocks.
+#define PACK_MAX_SEGS 26
+struct PackPlan { int n, Lp, Ld, Lt; int first_block[PACK_MAX_SEGS + 1]; PackSeg seg[PACK_MAX_SEGS]; };
+static_assert(sizeof(PackPlan) <= 3800, "a pack plan must fit the kernel-argument segment");
+
+__global__ void __launch_bounds__(256) pack_plan_kernel(PackPlan P) {
+    int k = 0;
+    while (k + 1 < P.n && (int)blockIdx.x >= P.first_block[k + 1]) ++k;        // block-uniform
+    const PackSeg& s = P.seg[k];
+    const int e = ((int)blockIdx.x - P.first_block[k]) * 256 + threadIdx.x;
+    if (s.kind == 1) {
+        if (e < SW_BIAS_TILE_FLOATS) {
+            const int r = e & 15;
+            s.dstB[e] = r < s.out_dim ? s.W[r] : ((r - s.out_dim) < s.in_dim ? s.b[r - s.out_dim] : 0.f);
+        }
+        return;
+    }
+    const int nsteps = s.max_steps > 0 ? s.max_steps : s.NT * s.KT * 4;
     if (e < nsteps * SW_STEP_FLOATS) {
         const int step = e / SW_STEP_FLOATS, rem = e % SW_STEP_FLOATS;
         const int lane = rem >> 2, i4 = rem & 3;
@@ -45,39 +67,31 @@ __global__ void __launch_bounds__(256) pack_seg_kernel(PackSeg s) {
         int col = -1;
         switch (s.ktype[kt]) {
             case KT_TRUNK: col = sw_frow(r, h); break;
-            case KT_POS0: col = sw_pos_col(r, h, s.Lp); break;
-            case KT_POS1: col = sw_pos_col(16 + r, h, s.Lp); break;
-            case KT_DIR: col = sw_dir_col(r, h, s.Ld); break;
-            case KT_TIME: col = sw_time_col(r, h, s.Lt); break;
+            case KT_POS0: col = sw_pos_col(r, h, P.Lp); break;
+            case KT_POS1: col = sw_pos_col(16 + r, h, P.Lp); break;
+            case KT_DIR: col = sw_dir_col(r, h, P.Ld); break;
+            case KT_TIME: col = sw_time_col(r, h, P.Lt); break;
         }
         float v = 0.f;
         if (!s.transpose) {
             if (row < s.out_dim && col >= 0) v = s.W[(size_t)row * s.in_dim + s.kbase[kt] + col];
         } else {
-            const int k = s.kbase[kt] + col;
+            const int kk = s.kbase[kt] + col;
             int wcol = row;
             if (s.rowmap) {
                 const int hh = (i >> 2) & 1, rr = (i & 3) + 4 * (i >> 3);      // inverse of sw_frow
-                wcol = sw_pos_col(16 * n + rr, hh, s.Lp);
+                wcol = sw_pos_col(16 * n + rr, hh, P.Lp);
             }
-            if (wcol >= 0 && wcol < s.out_dim && k < s.kvalid) v = s.W[(size_t)k * s.in_dim + s.row0 + wcol];
+            if (wcol >= 0 && wcol < s.out_dim && kk < s.kvalid) v = s.W[(size_t)kk * s.in_dim + s.row0 + wcol];
         }
         s.dstW[e] = v;
     }
-    if (s.b && e < s.NT * SW_BIAS_TILE_FLOATS) {
+    if (s.b && s.max_steps == 0 && e < s.NT * SW_BIAS_TILE_FLOATS) {
         const int n = e / SW_BIAS_TILE_FLOATS, rem = e % SW_BIAS_TILE_FLOATS;
         const int h = rem >> 4, r = rem & 15;
         const int row = 32 * n + sw_frow(r, h);
         s.dstB[e] = (row < s.out_dim) ? s.b[row] : 0.f;
     }
-}
-
-// head-bias tile: [h][r] = (b_a ++ b_b)[r] for r < n_a + n_b, the same in both lane halves, else 0
-__global__ void pack_headbias_kernel(float* dst, const float* b_a, int n_a, const float* b_b, int n_b) {
-    const int e = threadIdx.x;
-    if (e >= SW_BIAS_TILE_FLOATS) return;
-    const int r = e & 15;
-    dst[e] = r < n_a ? b_a[r] : ((r - n_a) < n_b ? b_b[r - n_a] : 0.f);
 }
 
 // feature_linear folded into views_linears.0 (swnerf_common.h, SW_CANON_STEPS): fold[u][i] = sum_o Wv[u][o] W_f[o][i] for
@@ -109,61 +123,85 @@ static int fold_views(const float* const* params, int Cdir, float* fold, hipStre
     return sw_check(hipGetLastError(), "pack_net fold launch");
 }
 
+// Collects the segments of a stream (weights advance `w`, bias-style tiles advance `b`) and launches them as ONE kernel:
+// flush() (also called when the plan is full).  Nothing is launched before that - order writes that other kernels read
+// (the fold) IN FRONT of the first flush on the same stream.
 struct Packer {
     hipStream_t st; float* w; float* b; int Lp, Ld, Lt; int rc;
-    void seg(const float* W, const float* bias, int out_dim, int in_dim, int NT, int KT, const int* kt, const int* kb) {
+    PackPlan plan;
+    PackSeg head; bool have_head;                        // the stream's first weight segment (its first SW_TAIL steps are the ring tail)
+    Packer(hipStream_t st_, float* w_, float* b_, int Lp_, int Ld_, int Lt_) : st(st_), w(w_), b(b_), Lp(Lp_), Ld(Ld_), Lt(Lt_), rc(0), have_head(false) {
+        plan.n = 0; plan.first_block[0] = 0;
+    }
+    void push(const PackSeg& s, int threads) {
         if (rc) return;
+        if (plan.n == PACK_MAX_SEGS) flush();
+        plan.seg[plan.n] = s;
+        plan.first_block[plan.n + 1] = plan.first_block[plan.n] + (threads + 255) / 256;
+        ++plan.n;
+    }
+    int flush() {
+        if (rc || plan.n == 0) return rc;
+        plan.Lp = Lp; plan.Ld = Ld; plan.Lt = Lt;
+        hipLaunchKernelGGL(pack_plan_kernel, dim3(plan.first_block[plan.n]), dim3(256), 0, st, plan);
+        rc = sw_check(hipGetLastError(), "pack_net launch");
+        plan.n = 0; plan.first_block[0] = 0;
+        return rc;
+    }
+    static PackSeg blank() {
         PackSeg s;
-        s.W = W; s.b = bias; s.out_dim = out_dim; s.in_dim = in_dim; s.NT = NT; s.KT = KT;
-        for (int i = 0; i < 10; ++i) { s.ktype[i] = i < KT ? kt[i] : 0; s.kbase[i] = i < KT ? kb[i] : 0; }
-        s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
-        s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
-        launch(s, NT, KT, bias != nullptr);
+        s.W = nullptr; s.b = nullptr; s.dstW = nullptr; s.dstB = nullptr; s.out_dim = 0; s.in_dim = 0; s.NT = 0; s.KT = 0;
+        s.transpose = 0; s.rowmap = 0; s.row0 = 0; s.kvalid = 0; s.max_steps = 0; s.kind = 0;
+        for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
+        return s;
+    }
+    void seg(const float* W, const float* bias, int out_dim, int in_dim, int NT, int KT, const int* kt, const int* kb) {
+        PackSeg s = blank();
+        s.W = W; s.b = bias; s.out_dim = out_dim; s.in_dim = in_dim; s.NT = (short)NT; s.KT = (short)KT;
+        for (int i = 0; i < KT; ++i) { s.ktype[i] = (unsigned char)kt[i]; s.kbase[i] = (short)kb[i]; }
+        s.dstW = w; s.dstB = b;
+        if (!have_head) { head = s; have_head = true; }
+        push(s, NT * KT * 4 * SW_STEP_FLOATS);
+        w += NT * KT * 4 * SW_STEP_FLOATS;
+        if (bias) b += NT * SW_BIAS_TILE_FLOATS;
     }
     // transposed segment of the backward stream: out rows = W columns [row0, row0+n_out), k = W rows [0, kvalid)
     void segT(const float* W, int w_rows, int w_cols, int row0, int n_out, int NT, int KT, int rowmap = 0) {
-        if (rc) return;
-        PackSeg s;
-        s.W = W; s.b = nullptr; s.out_dim = n_out; s.in_dim = w_cols; s.NT = NT; s.KT = KT;
-        for (int i = 0; i < 10; ++i) { s.ktype[i] = KT_TRUNK; s.kbase[i] = 32 * i; }
-        s.Lp = Lp; s.Ld = Ld; s.Lt = Lt; s.dstW = w; s.dstB = b;
-        s.transpose = 1; s.row0 = row0; s.kvalid = w_rows; s.rowmap = rowmap;
-        launch(s, NT, KT, false);
+        PackSeg s = blank();
+        s.W = W; s.out_dim = n_out; s.in_dim = w_cols; s.NT = (short)NT; s.KT = (short)KT;
+        for (int i = 0; i < KT; ++i) { s.ktype[i] = KT_TRUNK; s.kbase[i] = (short)(32 * i); }
+        s.dstW = w; s.dstB = b;
+        s.transpose = 1; s.row0 = row0; s.kvalid = w_rows; s.rowmap = (short)rowmap;
+        if (!have_head) { head = s; have_head = true; }
+        push(s, NT * KT * 4 * SW_STEP_FLOATS);
+        w += NT * KT * 4 * SW_STEP_FLOATS;
     }
-    void launch(PackSeg& s, int NT, int KT, bool has_bias) {
-        const int total = NT * KT * 4 * SW_STEP_FLOATS;
-        hipLaunchKernelGGL(pack_seg_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s);
-        rc = sw_check(hipGetLastError(), "pack_net launch");
-        w += total;
-        if (has_bias) b += NT * SW_BIAS_TILE_FLOATS;
+    // the ring tail: the first SW_TAIL steps of the stream that starts with segment `first` once more, at the current `w`
+    // (the head segment must hold at least SW_TAIL steps: every stream here starts with one of >= 16)
+    void tail() {
+        if (rc) return;
+        if (!have_head || head.NT * head.KT * 4 < SW_TAIL) { rc = sw_fail(SWNERF_E_ARG, "pack_net: a stream's head segment is shorter than its ring tail"); return; }
+        PackSeg s = head;
+        s.b = nullptr; s.dstW = w; s.max_steps = SW_TAIL;
+        push(s, SW_TAIL * SW_STEP_FLOATS);
+        w += SW_TAIL * SW_STEP_FLOATS;
     }
     // `nout` weight rows of length `in_dim` (a multiple of 32) as bias-style tiles, for head_valu
     void vecs(const float* W, int nout, int in_dim) {
-        for (int o = 0; o < nout && !rc; ++o) {
-            PackSeg s;
-            s.W = W; s.b = W + (size_t)o * in_dim; s.out_dim = in_dim; s.in_dim = in_dim; s.NT = in_dim / 32; s.KT = 0;
-            for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
-            s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
-            hipLaunchKernelGGL(pack_seg_kernel, dim3((s.NT * SW_BIAS_TILE_FLOATS + 255) / 256), dim3(256), 0, st, s);
-            rc = sw_check(hipGetLastError(), "pack_net launch");
-            b += s.NT * SW_BIAS_TILE_FLOATS;
-        }
+        for (int o = 0; o < nout; ++o) btiles(W + (size_t)o * in_dim, in_dim, in_dim / 32);
     }
     // NT bias tiles of `bias` [out_dim] alone (no weight steps)
     void btiles(const float* bias, int out_dim, int NT) {
-        if (rc) return;
-        PackSeg s;
-        s.W = bias; s.b = bias; s.out_dim = out_dim; s.in_dim = out_dim; s.NT = NT; s.KT = 0;
-        for (int i = 0; i < 10; ++i) { s.ktype[i] = 0; s.kbase[i] = 0; }
-        s.Lp = s.Ld = s.Lt = 0; s.dstW = w; s.dstB = b; s.transpose = 0; s.row0 = 0; s.kvalid = 0; s.rowmap = 0;
-        hipLaunchKernelGGL(pack_seg_kernel, dim3((NT * SW_BIAS_TILE_FLOATS + 255) / 256), dim3(256), 0, st, s);
-        rc = sw_check(hipGetLastError(), "pack_net launch");
+        PackSeg s = blank();
+        s.W = bias; s.b = bias; s.out_dim = out_dim; s.in_dim = out_dim; s.NT = (short)NT; s.KT = 0;
+        s.dstW = w; s.dstB = b;
+        push(s, NT * SW_BIAS_TILE_FLOATS);
         b += NT * SW_BIAS_TILE_FLOATS;
     }
     void headbias(const float* b_a, int n_a, const float* b_b, int n_b) {
-        if (rc) return;
-        hipLaunchKernelGGL(pack_headbias_kernel, dim3(1), dim3(64), 0, st, b, b_a, n_a, b_b, n_b);
-        rc = sw_check(hipGetLastError(), "pack_net launch");
+        PackSeg s = blank();
+        s.kind = 1; s.W = b_a; s.b = b_b; s.out_dim = n_a; s.in_dim = n_b; s.dstB = b;
+        push(s, SW_BIAS_TILE_FLOATS);
         b += SW_BIAS_TILE_FLOATS;
     }
     // one 8-layer trunk; P = {W0,b0,...,W7,b7}.  The head (Wh [head_out,256], bh) goes to the bias tiles.
@@ -211,36 +249,32 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
         pk.seg(fold, fold + 128 * SW_FOLD_LD, 128, SW_FOLD_LD, 4, 9, vt, vb);      // VIEWSF on [h7 | gamma(d)]
         pk.vecs(params[22], 3, 128);                                               // rgb_linear.weight
     };
-    auto tail = [&](float* wbase, const float* head) {
-        return sw_check(hipMemcpyAsync(wbase, head, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net tail copy");
-    };
-
     if (kind == SWNERF_NET_DNERF) {
-        Packer pk{st, packed, packed + SW_DNERF_W_FLOATS, L_pos, L_dir, L_time, 0};
+        Packer pk(st, packed, packed + SW_DNERF_W_FLOATS, L_pos, L_dir, L_time);
         pk.trunk(params + 24, params[40], params[41], 3, Cpos, Ctime);             // deformation net
         canon(pk);
-        if (pk.rc) return pk.rc;
-        if (pk.w != packed + (size_t)(SW_DEFORM_STEPS + SW_CANON_STEPS) * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
-        if ((rc = tail(pk.w, packed))) return rc;
+        if (!pk.rc && pk.w != packed + (size_t)(SW_DEFORM_STEPS + SW_CANON_STEPS) * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
+        pk.tail();
+        if ((rc = pk.flush())) return rc;
         packed += SW_DNERF_A_FLOATS;                                               // then the canon-only blob
     }
-    Packer pk{st, packed, packed + SW_CANON_W_FLOATS, L_pos, L_dir, L_time, 0};
+    Packer pk(st, packed, packed + SW_CANON_W_FLOATS, L_pos, L_dir, L_time);
     canon(pk);
-    if (pk.rc) return pk.rc;
-    if (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_VL_OFFSET)
+    if (!pk.rc && (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_VL_OFFSET))
         return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
-    if ((rc = tail(pk.w, packed))) return rc;
+    pk.tail();
+    if ((rc = pk.flush())) return rc;
     // the view branch once more, as a stream that wraps onto itself (biases: the tiles packed above)
-    Packer vl{st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time, 0};
+    Packer vl(st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time);
     vl.seg(fold, nullptr, 128, SW_FOLD_LD, 4, 9, vt, vb);
-    if (vl.rc) return vl.rc;
-    return tail(vl.w, packed + SW_CANON_VL_OFFSET);
+    vl.tail();
+    return vl.flush();
 }
 
 // The canonical net's bias / head tiles in the UNFOLDED order (SW_X3_CANON_BIAS_TILES): what the bf16x3 core consumes, which
 // still runs feature_linear as its own layer (mlp_core_x3.h).  Called by swnerf_pack_net_x3_kind (x3_kernels.hip).
 int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStream_t st) {
-    Packer pk{st, nullptr, dst, 0, 0, 0, 0};
+    Packer pk(st, nullptr, dst, 0, 0, 0);
     for (int l = 0; l < 8; ++l) pk.btiles(params[2 * l + 1], 256, 8);                  // pts_linears.l.bias
     pk.vecs(params[20], 1, 256);                                                       // alpha_linear.weight
     pk.headbias(params[21], 1, params[23], 3);                                         // [b_alpha, b_r, b_g, b_b]
@@ -248,7 +282,7 @@ int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStrea
     pk.btiles(params[17], 128, 4);                                                     // views_linears.0.bias
     pk.vecs(params[22], 3, 128);                                                       // rgb_linear.weight
     if (!pk.rc && pk.b != dst + SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_x3: bias layout mismatch");
-    return pk.rc;
+    return pk.flush();
 }
 
 // use_viewdirs=False (model.py:59-60): the trunk alone; output_linear's rows ride as bias-style tiles like the other heads.
@@ -259,12 +293,12 @@ extern "C" int swnerf_pack_net_noview(const float* const* params, int L_pos, int
         return sw_fail(SWNERF_E_UNSUPP, "pack_net_noview: output_ch %d (the reference builds 4 or 5, nerf/run.py:231)", out_ch);
     for (int i = 0; i < 18; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_noview: params[%d] is NULL", i);
     hipStream_t st = (hipStream_t)stream;
-    Packer pk{st, packed, packed + SW_NOVIEW_W_FLOATS, L_pos, 0, 0, 0};
+    Packer pk(st, packed, packed + SW_NOVIEW_W_FLOATS, L_pos, 0, 0);
     pk.trunk(params, params[16], params[17], out_ch, 3 * (1 + 2 * L_pos), 0);
-    if (pk.rc) return pk.rc;
-    if (pk.w != packed + (size_t)SW_NOVIEW_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(out_ch) * SW_BIAS_TILE_FLOATS)
+    if (!pk.rc && (pk.w != packed + (size_t)SW_NOVIEW_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(out_ch) * SW_BIAS_TILE_FLOATS))
         return sw_fail(SWNERF_E_ARG, "pack_net_noview: internal layout mismatch");
-    return sw_check(hipMemcpyAsync(pk.w, packed, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_noview tail copy");
+    pk.tail();
+    return pk.flush();
 }
 
 // The backward (dX chain) streams: transposed weights in the order the backward kernels consume them
@@ -291,21 +325,22 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
     auto tail = [&](Packer& pk, size_t steps) {
         if (pk.rc) return pk.rc;
         if (pk.w != packed_bwd + steps * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd: internal layout mismatch");
-        return sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd tail copy");
+        pk.tail();
+        return pk.rc;
     };
     if (bwd_kind == SWNERF_BWD_DEFORM) {
-        Packer pk{st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, L_dir, 0, 0};
+        Packer pk(st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, L_dir, 0);
         for (int l = 7; l >= 1; --l)                                  // _time.l.weight[:, -256:]^T
             pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
         int rc = tail(pk, SW_DBWD_STEPS);
         if (rc) return rc;
         pk.vecs(params[16], 3, 256);                                  // _time_out.weight rows, tile n: [h][r] = w[o][32n + frow(r,h)]
-        return pk.rc;
+        return pk.flush();
     }
     const bool fused = bwd_kind == SWNERF_BWD_DNERF_FUSED;
     const bool ig = bwd_kind == SWNERF_BWD_CANON_INPUT_GRAD || fused;
     const size_t wfloats = fused ? SW_BWD_DN_W_FLOATS : (ig ? SW_BWD_IG_W_FLOATS : SW_BWD_W_FLOATS);
-    Packer pk{st, packed_bwd, packed_bwd + wfloats, L_pos, L_dir, 0, 0};
+    Packer pk(st, packed_bwd, packed_bwd + wfloats, L_pos, L_dir, 0);
     // d h7 = W_vf^T . d pre_hv (the fold of swnerf_pack_net, recomputed into this blob's scratch behind the bias tiles)
     float* fold = packed_bwd + wfloats + (SW_BWD_BIAS_TILES + (fused ? 24 : 0)) * SW_BIAS_TILE_FLOATS;
     int rcf = fold_views(params, Cdir, fold, st);
@@ -324,7 +359,7 @@ extern "C" int swnerf_pack_net_bwd_kind(int bwd_kind, const float* const* params
     if (rc) return rc;
     pk.vecs(params[20], 1, 256);                                     // alpha_linear.weight [1,256] as 8 bias-style tiles
     if (fused) pk.vecs(params[40], 3, 256);                          // _time_out.weight rows as 3 x 8 tiles
-    return pk.rc;
+    return pk.flush();
 }
 
 // The dX chain's stream of the net without view directions: pts_linears.7 .. .1 transposed (trunk columns), then
@@ -337,15 +372,13 @@ extern "C" int swnerf_pack_net_bwd_noview(const float* const* params, int L_pos,
     for (int i = 0; i < 18; ++i) if (!params[i]) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: params[%d] is NULL", i);
     const int Cpos = 3 * (1 + 2 * L_pos);
     hipStream_t st = (hipStream_t)stream;
-    Packer pk{st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, 0, 0, 0};
+    Packer pk(st, packed_bwd, packed_bwd + SW_DBWD_W_FLOATS, L_pos, 0, 0);
     for (int l = 7; l >= 1; --l)                                  // pts_linears.l.weight[:, -256:]^T
         pk.segT(params[2 * l], 256, l == 5 ? Cpos + 256 : 256, l == 5 ? Cpos : 0, 256, 8, 8);
-    if (pk.rc) return pk.rc;
-    if (pk.w != packed_bwd + (size_t)SW_DBWD_STEPS * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: internal layout mismatch");
-    int rc = sw_check(hipMemcpyAsync(pk.w, packed_bwd, (size_t)SW_TAIL * SW_STEP_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, st), "pack_net_bwd_noview tail copy");
-    if (rc) return rc;
+    if (!pk.rc && pk.w != packed_bwd + (size_t)SW_DBWD_STEPS * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_bwd_noview: internal layout mismatch");
+    pk.tail();
     pk.vecs(params[16], out_ch, 256);                             // output_linear.weight rows, tile n: [h][r] = w[c][32n + frow(r,h)]
-    return pk.rc;
+    return pk.flush();
 }
 
 extern "C" int swnerf_pack_net_bwd(const float* const* params, int L_pos, int L_dir, float* packed_bwd, void* stream) {

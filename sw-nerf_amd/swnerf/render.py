@@ -276,8 +276,7 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
-        from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish, _Fan,
-                            _noview_slot_buffers, _noview_weight_grads_slots, _noview_unslot, _chunk_gemms, NARROW_FUSED)
+        from .wgrad import WeightGrads, _Fan, _chunk_gemms, NARROW_FUSED
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -286,12 +285,8 @@ class _FusedPassTrain(torch.autograd.Function):
         st = _lib.stream_of(rb)
         c = lambda g: None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_acc, g_raw = c(g_rgb), c(g_disp), c(g_acc), c(g_raw)
-        g = _zero_grads(params)
         nv = ctx.noview
-        if nv:
-            slot_bufs, rgb4 = _noview_slot_buffers(rb.device), None
-        else:
-            slot_bufs, rgb4 = _slot_buffers(rb.device), _rgb4_buffers(rb.device)
+        wg = WeightGrads(L, "noview" if nv else "canon", params, fused=True, Cpos=net.input_ch, Cdir=0 if nv else net.input_ch_views, bands=(Lp, Ld, 0))
         # The gradient buffer [rows, 2432] is as large as the saved activations; the dX chain and the GEMMs that consume
         # it run per CHUNK of rays, so only one chunk of it is ever alive (GEMMs accumulate: C += A^T.B).  A chunk is
         # 393 216 rows at the C2 shape - large enough for the split-K GEMMs to fill the chip.
@@ -302,7 +297,7 @@ class _FusedPassTrain(torch.autograd.Function):
         sl = lambda t, r0, r1: None if t is None else t[r0:r1]
         grad = torch.empty((min(N, chunk) * rows_per_ray, act.shape[1]), dtype=torch.float32, device=rb.device)
         d_raw = torch.empty((min(N, chunk) * rows_per_ray, 8 if nv else 4), dtype=torch.float32, device=rb.device)
-        fan = _Fan(rb.device)                                    # the GEMMs of a chunk fan out over side streams (model._Fan)
+        fan = _Fan(rb.device)                                    # the GEMMs of a chunk fan out over side streams (wgrad._Fan)
         for r0 in range(0, N, chunk):
             r1 = min(N, r0 + chunk)
             n, m = r1 - r0, (r1 - r0) * rows_per_ray
@@ -315,18 +310,9 @@ class _FusedPassTrain(torch.autograd.Function):
             else:
                 _lib.check(L.swnerf_render_pass_backward(*common, *grads_in), "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
-            if nv:
-                job = lambda st_, part: _noview_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch, g, slot_bufs, part=part)
-            else:
-                job = lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], net.input_ch,
-                                                                  net.input_ch_views, g, slot_bufs, rgb4, part=part)
+            job = lambda st_, part: wg.chunk(st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], part=part)
             _chunk_gemms(L, fan, m, [job], rest_on_main=NARROW_FUSED and not nv)
-        if nv:
-            _noview_unslot(L, st, slot_bufs, Lp, g)
-        else:
-            _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, g, params)
-            _rgb4_finish(g, rgb4)
-        return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
+        return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(wg.finish(st), params))
 
 
 def render_pass_train(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand=None, noise=None, white_bkgd=False,

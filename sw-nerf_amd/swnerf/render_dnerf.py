@@ -118,8 +118,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_dx_up, _gz, g_raw):
-        from .model import (_zero_grads, _canon_weight_grads_slots, _slot_buffers, _unslot_weight_grads, _rgb4_buffers, _rgb4_finish,
-                            _deform_slot_buffers, _deform_weight_grads_slots, _deform_unslot, _Fan, _chunk_gemms, NARROW_FUSED)
+        from .wgrad import WeightGrads, _Fan, _chunk_gemms, NARROW_FUSED
         from . import render as _r
         rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
@@ -129,8 +128,9 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         st = _lib.stream_of(rb)
         c = lambda g: None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_acc, g_dx_up, g_raw = c(g_rgb), c(g_disp), c(g_acc), c(g_dx_up), c(g_raw)
-        g = _zero_grads(params)                                   # 24 `_occ` tensors then 18 `_time` / `_time_out`
-        slot_bufs, rgb4, dbufs = _slot_buffers(rb.device), _rgb4_buffers(rb.device), _deform_slot_buffers(rb.device)
+        Cpos, Cdir = net.input_ch, net.input_ch_views
+        wc = WeightGrads(L, "canon", params[:24], fused=True, Cpos=Cpos, Cdir=Cdir, bands=(Lp, Ld, Lt))       # the 24 `_occ` tensors
+        wd = WeightGrads(L, "deform", params[24:], fused=True, Cpos=Cpos, bands=(Lp, Ld, Lt))                 # the 18 `_time` / `_time_out`
         rows_per_ray = act.shape[0] // N
         # two gradient buffers (canonical + deformation net) per chunk: half of TRAIN_BWD_CHUNK_ROWS rows each, so that a chunk
         # holds the 3.8 GB the static backward's chunk does; the GEMMs of a chunk fan out over side streams (model._Fan), which
@@ -143,8 +143,6 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         nrow = min(N, chunk) * rows_per_ray
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=rb.device)
         grad, grad_d, d_raw, g_dx = new(nrow, act.shape[1]), new(nrow, act.shape[1]), new(nrow, 4), new(nrow, 4)
-        gc, gd = g[:24], g[24:]
-        Cpos, Cdir = net.input_ch, net.input_ch_views
         fan = _Fan(rb.device)
         for r0 in range(0, N, chunk):
             r1 = min(N, r0 + chunk)
@@ -158,13 +156,10 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
                 "render_pass_backward_dnerf")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
             _chunk_gemms(L, fan, m, [
-                lambda st_, part: _canon_weight_grads_slots(L, st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], Cpos, Cdir, gc, slot_bufs, rgb4, part=part),
-                lambda st_, part: _deform_weight_grads_slots(L, st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], Cpos, gd, dbufs, part=part)],
+                lambda st_, part: wc.chunk(st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], part=part),
+                lambda st_, part: wd.chunk(st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], part=part)],
                 rest_on_main=[NARROW_FUSED, False])
-        _unslot_weight_grads(L, st, slot_bufs, Lp, Ld, gc, params[:24])
-        _rgb4_finish(gc, rgb4)
-        _deform_unslot(L, st, dbufs, Lp, Lt, Cpos, gd)
-        g = gc + gd
+        g = wc.finish(st) + wd.finish(st)
         return (None,) * 8 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 
 

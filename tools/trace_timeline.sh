@@ -23,6 +23,28 @@ for r in rows[i0:i1]:
     if e - s >= 20000:
         print(f"| {s / 1e3:.0f} | {e / 1e3:.0f} | {(e - s) / 1e3:.0f} | {r.get('Queue_Id', '?')} | {r['Kernel_Name'].split('(')[0][-60:]} |")
 print(f"\nstep = {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.0f} us from first forward launch to the next step's")
+# the small launches (< 20 us) of the step, and how long the GPU sat idle between kernels
+from collections import defaultdict
+small = defaultdict(lambda: [0, 0])
+iv = []
+for r in rows[i0:i1]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    iv.append((s, e))
+    if e - s < 20000:
+        k = r["Kernel_Name"].split("(")[0][-50:]
+        small[k][0] += 1; small[k][1] += e - s
+iv.sort()
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+for s, e in iv[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s; cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+span = int(rows[i1]["Start_Timestamp"]) - t0
+print(f"GPU busy {busy / 1e3:.0f} us of {span / 1e3:.0f} us: idle between kernels {(span - busy) / 1e3:.0f} us; {sum(v[0] for v in small.values())} launches under 20 us take {sum(v[1] for v in small.values()) / 1e3:.0f} us:")
+for k, v in sorted(small.items(), key=lambda kv: -kv[1][1])[:14]:
+    print(f"  {v[0]:3d} x {k}: {v[1] / 1e3:.0f} us")
 PY
 grep -i "step" $OUT/$tag.log | grep -v rocprof | tail -3 >> $OUT/$tag.md
 rm -rf $OUT/trace_$tag
