@@ -360,6 +360,17 @@ int swnerf_feature_finish(const float* G, const float* db_hv, const float* Wv, i
 int swnerf_canon_narrow_grads(const float* grad, int ldg, const float* act, int lda, const float* xs, const float* d_out, int64_t M,
                               float* c0s, float* cvs, float* G, float* a4w, float* rgb4, float* b_l0, float* b_hv, float* a4b,
                               float* rgb4b, void* stream);
+/* The same for the other two nets (one launch per chunk each; table-driven narrow_plan_kernel, csrc/backward_kernels.hip):
+ * deformation net (`_time.0` = [gamma(x) | gamma(t)], `_time_out`; model.py:128-136): grad_d / act_d [M, ld >= 2432] (d pre_0 at
+ *   column 0, h7 at 1792), xs_d [M, 96] (gamma(x) slots 0..63, gamma(t) slots 64..95), g_dx [M, 4] = d dx with a zero 4th column:
+ *   c0s [256,64] += d pre_0^T xs_d[:, :64], cts [256,32] += d pre_0^T xs_d[:, 64:], w4 [4,256] += g_dx^T h7; b_l0 [256], b4 [4]
+ * net without view directions (pts_linears.0, output_linear; model.py:59-60): xs [M, 96], d_raw8 [M, 8] (columns >= out_ch zero):
+ *   c0s [256,64] += d pre_0^T xs[:, :64], w8 [8,256] += d_raw8^T h7; b_l0 [256], b8 [8].
+ * All operands 16-byte aligned, leading dimensions multiples of 4; outputs accumulate (atomics). */
+int swnerf_deform_narrow_grads(const float* grad_d, int ldg, const float* act_d, int lda, const float* xs_d, const float* g_dx, int64_t M,
+                               float* c0s, float* cts, float* w4, float* b_l0, float* b4, void* stream);
+int swnerf_noview_narrow_grads(const float* grad, int ldg, const float* act, int lda, const float* xs, const float* d_raw8, int64_t M,
+                               float* c0s, float* w8, float* b_l0, float* b8, void* stream);
 /* ... for xs_d: slots 64..95 hold gamma(t) (L_time bands) instead of gamma(d) */
 int swnerf_unslot_grad_time(const float* Cs, int ld_s, int rows_w, int nslots, int L_time, float* W, int ldw, int col0, void* stream);
 

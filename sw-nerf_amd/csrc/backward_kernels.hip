@@ -954,6 +954,245 @@ extern "C" int swnerf_canon_narrow_grads(const float* grad, int ldg, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same idea for ANY set of narrow products over the same rows, table driven (round 4): the deformation net's
+// (`_time.0` against gamma(x) and gamma(t), `_time_out`) and the no-view net's (pts_linears.0 against gamma(x), output_linear)
+// used to be two or three skinny GEMM launches per chunk, each re-reading d pre_0 or h7.  A plan names up to NP_MAX_OPS operand
+// windows (pointer, leading dimension, staged width), gives every wave ONE A operand and ONE B operand with four (A column,
+// B column) tile offsets - the single code path of narrow5_kernel, whose role tables are data here - and deals the slab's
+// 1-KiB DMA pieces out over the 16 waves.  NP_SLAB-row slabs, double buffered by LDS-DMA, one barrier per slab.
+// Measured (profiles/r04/narrow_plan.md): the deformation net's set 183 us per 196 608-row chunk in ONE launch on the main stream
+// against ~205 us for its three skinny GEMMs; the no-view net's set 304 us against 254 us - two padded products on 8 of 16 waves
+// are matrix-pipe bound there (16 + 8 tiles of 64-cycle MFMAs per row pair on four SIMDs) - so that net keeps its GEMMs.
+#ifndef NP_SLAB
+#define NP_SLAB 16                // rows per slab (32 fit the LDS for the plans below but measured 5-10 % slower: profiles/r04/narrow_plan.md)
+#endif
+#define NP_MAX_OPS 4
+#define NP_MAX_JOBS 5
+struct NpOp { const float* ptr; int ld; int width; int lds_off; int kib; };      // width: floats staged per row (multiple of 4); kib: 1-KiB pieces per slab image
+struct NpWave {
+    short a_op, b_op;              // operand indices; a_op < 0: this wave only helps with the DMA
+    short alim;                    // valid A columns of a 32-column block (4 / 8 for d dx / d raw, else 32)
+    short rlim, cshift, bias_lim;  // output rows < rlim; C column = B column - cshift; bias entries < bias_lim per block
+    short acol[4], bcol[4];
+    float* C; int ldc; int bias_mask;   // bit k: the column sums of this wave's A block k go to bias[acol[k] + i]
+    float* bias;
+    unsigned char job_op[NP_MAX_JOBS]; unsigned char job_kib[NP_MAX_JOBS];      // DMA duty: piece job_kib of operand job_op (255: none)
+};
+struct NpPlan { int64_t M, rows_per_wg; int buf_floats; NpOp op[NP_MAX_OPS]; NpWave wave[16]; };
+
+__global__ void __launch_bounds__(1024) narrow_plan_kernel(NpPlan P) {
+    extern __shared__ __attribute__((aligned(16))) float np_lds[];          // [2][buf_floats]
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const NpWave& R = P.wave[w];
+    const int64_t m0 = (int64_t)blockIdx.x * P.rows_per_wg;
+    const int mlen = (int)(min(P.M, m0 + P.rows_per_wg) - m0);
+    const int nslab = (mlen + NP_SLAB - 1) / NP_SLAB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)np_lds);
+    // DMA duties: piece q of operand o = bytes [1024 q, 1024 q + 1024) of the slab's dense [NP_SLAB][width] image; lane's 16 bytes
+    // sit in image row `jrow`, at byte `jcb` of it.  Per slab the wave-uniform base advances by NP_SLAB rows; only the slice's last,
+    // partial slab clamps its rows.  Lanes past the image (its size is not always a multiple of 1 KiB) re-read its first bytes.
+    const char* jbase[NP_MAX_JOBS];
+    unsigned jvoff[NP_MAX_JOBS], jlds[NP_MAX_JOBS], jrow[NP_MAX_JOBS], jcb[NP_MAX_JOBS], jpitch[NP_MAX_JOBS];
+    int64_t jstep[NP_MAX_JOBS];
+    bool jon[NP_MAX_JOBS];
+#pragma unroll
+    for (int j = 0; j < NP_MAX_JOBS; ++j) {
+        jon[j] = R.job_op[j] != 255;
+        const NpOp& O = P.op[jon[j] ? R.job_op[j] : 0];
+        const unsigned rowb = (unsigned)O.width * 4u, b = (unsigned)R.job_kib[j] * 1024u + (unsigned)lane * 16u;
+        const bool in = b < rowb * NP_SLAB;
+        jrow[j] = in ? b / rowb : 0u;
+        jcb[j] = in ? b - jrow[j] * rowb : 0u;
+        jpitch[j] = (unsigned)O.ld * 4u;
+        jvoff[j] = jrow[j] * jpitch[j] + jcb[j];
+        jbase[j] = reinterpret_cast<const char*>(O.ptr + m0 * O.ld);
+        jstep[j] = (int64_t)NP_SLAB * O.ld * 4;
+        jlds[j] = (unsigned)(O.lds_off * 4) + (unsigned)R.job_kib[j] * 1024u;
+    }
+    auto issue = [&](int sl) {
+        const unsigned buf = lds0 + (unsigned)((sl & 1) * P.buf_floats * 4);
+        const int valid = mlen - sl * NP_SLAB;
+#pragma unroll
+        for (int j = 0; j < NP_MAX_JOBS; ++j) {
+            if (!jon[j]) continue;                                   // wave-uniform
+            const unsigned vo = valid >= NP_SLAB ? jvoff[j] : min(jrow[j], (unsigned)(valid - 1)) * jpitch[j] + jcb[j];
+            ws_dma(jbase[j], vo, buf + jlds[j]);
+            jbase[j] += jstep[j];
+        }
+    };
+    const bool active = R.a_op >= 0;
+    const NpOp& OA = P.op[active ? R.a_op : 0];
+    const NpOp& OB = P.op[active ? R.b_op : 0];
+    const int asrc = OA.lds_off, ap = OA.width, bsrc = OB.lds_off, bp = OB.width, alim = R.alim;
+    int acol[4], bcol[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acol[k] = R.acol[k]; bcol[k] = R.bcol[k]; }
+    const bool acolumn = i < alim;
+    f32x16 acc[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    issue(0);
+#pragma nounroll
+    for (int sl = 0; sl < nslab; ++sl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+        if (sl + 1 < nslab) issue(sl + 1);
+        if (!active) continue;
+        const int valid = mlen - sl * NP_SLAB;
+        int pa[4], pb[4];
+        float a[4], b[4];
+        const int ia = (sl & 1) * P.buf_floats + asrc + (acolumn ? i : 0) + hp * ap, ib = (sl & 1) * P.buf_floats + bsrc + i + hp * bp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pa[k] = ia + acol[k]; pb[k] = ib + bcol[k]; a[k] = np_lds[pa[k]]; b[k] = np_lds[pb[k]]; }
+#pragma unroll 2
+        for (int s = 0; s < NP_SLAB / 2; ++s) {
+            const bool ok = acolumn && (2 * s + hp) < valid;
+            float c[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; pa[k] += 2 * ap; pb[k] += 2 * bp; }
+            // (the last prefetch reads two rows past the slab image: the next operand's region or the pad behind the buffer)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = np_lds[pa[k]]; b[k] = np_lds[pb[k]]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bs[k] += c[k];
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[k], d[k], acc[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32, 64);          // rows 2s and 2s+1 sit in the two lane halves
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = acol[k] + sw_frow(r, hp);
+            if (o < R.rlim) atomicAdd(R.C + (size_t)o * R.ldc + bcol[k] - R.cshift + i, acc[k][r]);
+        }
+    if (hp == 0 && R.bias && i < R.bias_lim) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((R.bias_mask >> k) & 1) atomicAdd(R.bias + acol[k] + i, bs[k]);
+    }
+}
+
+// host side: lay the operands out in the slab buffer, deal the DMA pieces out over the waves, launch
+struct NpBuilder {
+    NpPlan P; int n_ops, cursor;
+    NpBuilder(int64_t M) : n_ops(0), cursor(0) {
+        P.M = M;
+        for (int w = 0; w < 16; ++w) {
+            NpWave& R = P.wave[w];
+            R.a_op = -1; R.b_op = 0; R.alim = 32; R.rlim = 0; R.cshift = 0; R.bias_lim = 32; R.C = nullptr; R.ldc = 0; R.bias_mask = 0; R.bias = nullptr;
+            for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = 0; }
+            for (int j = 0; j < NP_MAX_JOBS; ++j) { R.job_op[j] = 255; R.job_kib[j] = 0; }
+        }
+        for (int o = 0; o < NP_MAX_OPS; ++o) { P.op[o].ptr = nullptr; P.op[o].ld = 0; P.op[o].width = 4; P.op[o].lds_off = 0; P.op[o].kib = 0; }
+    }
+    int op(const float* ptr, int ld, int width) {
+        NpOp& O = P.op[n_ops];
+        O.ptr = ptr; O.ld = ld; O.width = width; O.lds_off = cursor;
+        O.kib = (NP_SLAB * width * 4 + 1023) / 1024;
+        cursor += O.kib * 256;                               // whole KiB pieces: a DMA instruction always writes 1 KiB
+        return n_ops++;
+    }
+    NpWave& wave(int w, int a_op, int b_op, float* C, int ldc, int rlim) {
+        NpWave& R = P.wave[w];
+        R.a_op = (short)a_op; R.b_op = (short)b_op; R.C = C; R.ldc = ldc; R.rlim = (short)rlim;
+        return R;
+    }
+    int launch(const char* what, void* stream) {
+        int w = 0, slot[16] = {0};
+        for (int o = 0; o < n_ops; ++o)
+            for (int q = 0; q < P.op[o].kib; ++q) {
+                if (slot[w] == NP_MAX_JOBS) return sw_fail(SWNERF_E_ARG, "%s: too many DMA pieces per slab for the plan kernel", what);
+                P.wave[w].job_op[slot[w]] = (unsigned char)o; P.wave[w].job_kib[slot[w]] = (unsigned char)q;
+                ++slot[w];
+                w = (w + 1) & 15;
+            }
+        P.buf_floats = cursor + 2 * 256;                     // + the rows a last prefetch may touch
+        int64_t nwg = 256;
+        int64_t rows = ((P.M + nwg - 1) / nwg + NP_SLAB - 1) / NP_SLAB * NP_SLAB;
+        nwg = (P.M + rows - 1) / rows;
+        P.rows_per_wg = rows;
+        int maxld = 0;
+        for (int o = 0; o < n_ops; ++o) maxld = P.op[o].ld > maxld ? P.op[o].ld : maxld;
+        if (rows * (int64_t)maxld * 4 >= (1LL << 31)) return sw_fail(SWNERF_E_UNSUPP, "%s: row slice too large for 32-bit byte offsets", what);
+        hipLaunchKernelGGL(narrow_plan_kernel, dim3((unsigned)nwg), dim3(1024), 2 * (size_t)P.buf_floats * sizeof(float), (hipStream_t)stream, P);
+        return sw_check(hipGetLastError(), what);
+    }
+};
+
+static bool np_aligned(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+// Deformation net of DirectTemporalNeRF (model.py:128-136), fused D-NeRF training pass: over the M rows of a chunk
+//   c0s [256, 64] += d pre_0^T . xs_d[:, :64]     `_time.0`, gamma(x) slots        b_l0 [256] += column sums of d pre_0
+//   cts [256, 32] += d pre_0^T . xs_d[:, 64:96]   `_time.0`, gamma(t) slots
+//   w4  [4, 256]  += g_dx^T . h7                  `_time_out` = rows 0..2           b4 [4] += column sums of g_dx
+// grad_d / act_d: [M, ld >= 2432] (d pre_0 at column 0, h7 at 1792), xs_d [M, 96], g_dx [M, 4] (4th column zero).
+extern "C" int swnerf_deform_narrow_grads(const float* grad_d, int ldg, const float* act_d, int lda, const float* xs_d, const float* g_dx, int64_t M,
+                                          float* c0s, float* cts, float* w4, float* b_l0, float* b4, void* stream) {
+    if (M == 0) return 0;
+    if (!grad_d || !act_d || !xs_d || !g_dx || !c0s || !cts || !w4 || M < 0 || ldg < SW_ACT_LD || lda < SW_ACT_LD)
+        return sw_fail(SWNERF_E_ARG, "deform_narrow_grads: NULL pointer, negative M or a leading dimension below %d", SW_ACT_LD);
+    if (!np_aligned(grad_d) || !np_aligned(act_d) || !np_aligned(xs_d) || !np_aligned(g_dx) || ldg % 4 || lda % 4)
+        return sw_fail(SWNERF_E_ARG, "deform_narrow_grads: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    NpBuilder B(M);
+    const int o_g = B.op(grad_d, ldg, 256), o_x = B.op(xs_d, SW_XS_LD, SW_XS_LD), o_h = B.op(act_d + 1792, lda, 256), o_d = B.op(g_dx, 4, 4);
+    for (int w = 0; w < 4; ++w) {                                                // gamma(x) slots: A tiles 2w, 2w+1 x xs tiles 0, 1
+        NpWave& R = B.wave(w, o_g, o_x, c0s, 64, 256);
+        for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(64 * w + 32 * (k >> 1)); R.bcol[k] = (short)(32 * (k & 1)); }
+        R.bias = b_l0; R.bias_mask = 0x5;
+    }
+    for (int w = 4; w < 6; ++w) {                                                // gamma(t) slots: A tiles 4(w-4)..+3 x xs tile 2
+        NpWave& R = B.wave(w, o_g, o_x, cts, 32, 256);
+        for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(128 * (w - 4) + 32 * k); R.bcol[k] = 64; }
+        R.cshift = 64;
+    }
+    for (int w = 6; w < 8; ++w) {                                                // _time_out: d dx (4 columns) x h7 tiles 4(w-6)..+3
+        NpWave& R = B.wave(w, o_d, o_h, w4, 256, 4);
+        R.alim = 4;
+        for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = (short)(128 * (w - 6) + 32 * k); }
+        if (w == 6) { R.bias = b4; R.bias_mask = 0x1; R.bias_lim = 4; }
+    }
+    return B.launch("deform_narrow_grads launch", stream);
+}
+
+// The net without view directions (model.py:59-60), fused training pass:
+//   c0s [256, 64] += d pre_0^T . xs[:, :64]       pts_linears.0, gamma(x) slots      b_l0 [256] += column sums of d pre_0
+//   w8  [8, 256]  += d_raw8^T . h7                output_linear = rows 0..out_ch-1   b8 [8] += column sums of d_raw8
+// grad / act: [M, ld >= 2048 + ...] as above, xs [M, 96], d_raw8 [M, 8] (columns >= out_ch zero).
+extern "C" int swnerf_noview_narrow_grads(const float* grad, int ldg, const float* act, int lda, const float* xs, const float* d_raw8, int64_t M,
+                                          float* c0s, float* w8, float* b_l0, float* b8, void* stream) {
+    if (M == 0) return 0;
+    if (!grad || !act || !xs || !d_raw8 || !c0s || !w8 || M < 0 || ldg < SW_ACT_LD || lda < SW_ACT_LD)
+        return sw_fail(SWNERF_E_ARG, "noview_narrow_grads: NULL pointer, negative M or a leading dimension below %d", SW_ACT_LD);
+    if (!np_aligned(grad) || !np_aligned(act) || !np_aligned(xs) || !np_aligned(d_raw8) || ldg % 4 || lda % 4)
+        return sw_fail(SWNERF_E_ARG, "noview_narrow_grads: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    NpBuilder B(M);
+    const int o_g = B.op(grad, ldg, 256), o_x = B.op(xs, SW_XS_LD, SW_XS_LD), o_h = B.op(act + 1792, lda, 256), o_d = B.op(d_raw8, 8, 8);
+    for (int w = 0; w < 4; ++w) {
+        NpWave& R = B.wave(w, o_g, o_x, c0s, 64, 256);
+        for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(64 * w + 32 * (k >> 1)); R.bcol[k] = (short)(32 * (k & 1)); }
+        R.bias = b_l0; R.bias_mask = 0x5;
+    }
+    for (int w = 4; w < 6; ++w) {                                                // output_linear: d raw (8 columns) x h7 tiles 4(w-4)..+3
+        NpWave& R = B.wave(w, o_d, o_h, w8, 256, 8);
+        R.alim = 8;
+        for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = (short)(128 * (w - 4) + 32 * k); }
+        if (w == 4) { R.bias = b8; R.bias_mask = 0x1; R.bias_lim = 8; }
+    }
+    return B.launch("noview_narrow_grads launch", stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // feature_linear has no activation (model.py:50-51), so the fused training pass never stores `feature` or d feature and never
 // runs feature_linear's 256 x 256 weight-gradient GEMM: with G = sum_rows d pre_hv (x) h7 [128, 256] (one narrow GEMM) and
 // db_hv = sum_rows d pre_hv,

@@ -14,7 +14,7 @@ EXPORTS = ["swnerf_version", "swnerf_last_error", "swnerf_packed_floats", "swner
            "swnerf_get_rays", "swnerf_ndc_rays", "swnerf_pack_ray_batch", "swnerf_raw2outputs", "swnerf_raw2outputs_backward",
            "swnerf_sample_pdf", "swnerf_sample_coarse", "swnerf_embed", "swnerf_mlp_forward", "swnerf_query_points", "swnerf_render_pass",
            "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row", "swnerf_mask_floats", "swnerf_mlp_forward_train", "swnerf_pack_net_bwd",
-           "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused", "swnerf_gemm_tn_group", "swnerf_feature_finish", "swnerf_canon_narrow_grads",
+           "swnerf_mlp_backward_dx", "swnerf_gemm_tn", "swnerf_gemm_tn_fused", "swnerf_gemm_tn_group", "swnerf_feature_finish", "swnerf_canon_narrow_grads", "swnerf_deform_narrow_grads", "swnerf_noview_narrow_grads",
            "swnerf_packed_bwd_floats_kind", "swnerf_pack_net_bwd_kind", "swnerf_deform_forward_train",
            "swnerf_mlp_backward_dx_pts", "swnerf_deform_backward_dx",
            "swnerf_train_rows", "swnerf_xs_floats_per_row", "swnerf_render_pass_train", "swnerf_render_pass_backward", "swnerf_unslot_grad",
@@ -103,6 +103,8 @@ def lib():
                                        c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]
     L.swnerf_gemm_tn_group.argtypes = [POINTER(GemmItem), c_int, c_int64, c_void_p]
     L.swnerf_canon_narrow_grads.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64] + [c_void_p] * 10
+    L.swnerf_deform_narrow_grads.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64] + [c_void_p] * 6
+    L.swnerf_noview_narrow_grads.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64] + [c_void_p] * 5
     L.swnerf_feature_finish.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.swnerf_packed_bwd_floats_kind.restype = c_size_t

@@ -276,7 +276,7 @@ class _FusedPassTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, _gz, _gs, g_raw):
-        from .wgrad import WeightGrads, _Fan, _chunk_gemms, NARROW_FUSED
+        from .wgrad import WeightGrads, _Fan, _chunk_gemms, NARROW_FUSED, NOVIEW_NARROW_FUSED
         rb, z, raw, act, bits, xs, noise, *params = ctx.saved_tensors
         net, S = ctx.net, ctx.S
         Lp, Ld = ctx.bands
@@ -311,7 +311,7 @@ class _FusedPassTrain(torch.autograd.Function):
                 _lib.check(L.swnerf_render_pass_backward(*common, *grads_in), "render_pass_backward")
             a0, a1 = r0 * rows_per_ray, r1 * rows_per_ray
             job = lambda st_, part: wg.chunk(st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], part=part)
-            _chunk_gemms(L, fan, m, [job], rest_on_main=NARROW_FUSED and not nv)
+            _chunk_gemms(L, fan, m, [job], rest_on_main=NARROW_FUSED and (not nv or NOVIEW_NARROW_FUSED))
         return (None,) * 10 + tuple(gi.to(p.dtype) for gi, p in zip(wg.finish(st), params))
 
 

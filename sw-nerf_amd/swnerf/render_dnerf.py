@@ -158,7 +158,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
             _chunk_gemms(L, fan, m, [
                 lambda st_, part: wc.chunk(st_, m, grad[:m], act[a0:a1], xs[a0:a1], d_raw[:m], part=part),
                 lambda st_, part: wd.chunk(st_, m, grad_d[:m], act_d[a0:a1], xs_d[a0:a1], g_dx[:m], part=part)],
-                rest_on_main=[NARROW_FUSED, False])
+                rest_on_main=[NARROW_FUSED, NARROW_FUSED])
         g = wc.finish(st) + wd.finish(st)
         return (None,) * 8 + tuple(gi.to(p.dtype) for gi, p in zip(g, params))
 

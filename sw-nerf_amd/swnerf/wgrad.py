@@ -28,6 +28,7 @@ GEMM_STREAMS = int(os.environ.get("SWNERF_GEMM_STREAMS", "2"))    # side streams
 GEMM_GROUP = os.environ.get("SWNERF_GEMM_GROUP", "1") != "0"
 GROUP_RIDERS = os.environ.get("SWNERF_GEMM_GROUP", "1") != "plain"  # the skip layer's GEMM (gamma(x) rider) joins the group, at work weight 6 : 4
 NARROW_FUSED = os.environ.get("SWNERF_NARROW_FUSED", "1") != "0"     # a net's narrow weight-gradient products as one kernel
+NOVIEW_NARROW_FUSED = os.environ.get("SWNERF_NOVIEW_NARROW_FUSED", "0") == "1"
 _SIDE_STREAMS = {}
 
 
@@ -258,9 +259,22 @@ class WeightGrads:
                 mm(draw, 3, 1, act, SW_ACT_H7, 256, s["a4w"], 3 * 256, s["a4b"][3:])      # row 3 of the 4-row form
                 mm(draw, 0, 3, act, SW_ACT_HV, 128, s["rgb4w"], 0, s["rgb4b"])
         elif self.kind == "noview":
+            # (the fused kernel exists for this net too but measures slower than its two skinny GEMMs - 304 vs 254 us per 393 216-row
+            # chunk, profiles/r04/narrow_plan.md - so it is opt-in)
+            if (self.fused and NOVIEW_NARROW_FUSED and draw.stride(0) == 8 and grad.stride(0) == act.stride(0) and enc.stride(0) == 96
+                    and not (grad.data_ptr() | act.data_ptr() | enc.data_ptr() | draw.data_ptr()) % 16):
+                _lib.check(L.swnerf_noview_narrow_grads(_lib.ptr(grad), grad.stride(0), _lib.ptr(act), act.stride(0), _lib.ptr(enc), _lib.ptr(draw), M,
+                                                        _lib.ptr(s["c0s"]), _lib.ptr(s["w8"]), _lib.ptr(g[1]), _lib.ptr(s["b8"]), _st(st)), "noview_narrow_grads")
+                return
             mm(grad, 0, 256, enc, 0, e0, c0[0], c0[1], g[1])                               # pts_linears.0
             mm(draw, 0, 8, act, SW_ACT_H7, 256, s["w8"], 0, s["b8"])                       # output_linear (rows 0..out_ch-1)
         else:
+            if (self.fused and NARROW_FUSED and aligned4 and grad.stride(0) == act.stride(0) and enc.stride(0) == 96
+                    and not (grad.data_ptr() | act.data_ptr() | enc.data_ptr()) % 16):
+                _lib.check(L.swnerf_deform_narrow_grads(_lib.ptr(grad), grad.stride(0), _lib.ptr(act), act.stride(0), _lib.ptr(enc), _lib.ptr(draw), M,
+                                                        _lib.ptr(s["c0s"]), _lib.ptr(s["cts"]), _lib.ptr(s["w4"]), _lib.ptr(g[1]), _lib.ptr(s["b4"]), _st(st)),
+                           "deform_narrow_grads")
+                return
             ct = (s["cts"], 0, enc, 64, 32) if self.fused else (g[0], Cpos, enc2, 0, self.Ct)
             mm(grad, 0, 256, enc, 0, e0, c0[0], c0[1], g[1])                               # _time.0 = [gamma(x) | gamma(t)]
             mm(grad, 0, 256, ct[2], ct[3], ct[4], ct[0], ct[1], None)
