@@ -130,6 +130,7 @@ def fused_plan(network_query_fn, nets, need_time=False, allow_train=False):
 # coarse weights, so last-bit differences there move fine samples), bf16x3 for every other pass: the depths, rgb0 and z_std
 # are then exactly the fp32 path's and the image differs by the MLP rounding alone.
 _PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16x3-fine": 3, "bf16": 1}
+_WARNED = {}
 PRECISION = os.environ.get("SWNERF_PRECISION", "fp32")
 if PRECISION not in _PRECISIONS:
     raise ValueError(f"swnerf: SWNERF_PRECISION={PRECISION!r} is not one of {sorted(_PRECISIONS)}")
@@ -169,6 +170,11 @@ def render_pass(ray_batch, net, n_samples, *, z_vals=None, lindisp=False, t_rand
     if noview:                                           # the fp32 pass without the view branch (SWNERF_NET_NOVIEW)
         packed, Lp, out_ch = net.packed_noview()
         kind, Ld, Lt, terms = _lib.NET_NOVIEW, 0, 0, 0
+        if _PRECISIONS[PRECISION if precision is None else precision] and not _WARNED.get("noview_x3"):
+            _WARNED["noview_x3"] = True
+            import warnings
+            warnings.warn(f"swnerf: precision {PRECISION if precision is None else precision!r} was requested, but the bf16 paths are built for the "
+                          "nets WITH view directions only - this use_viewdirs=False net renders in fp32 (label your numbers accordingly)")
     else:
         kind, packed, Lp, Ld, Lt = net.packed()
         mode = PRECISION if precision is None else precision
@@ -588,21 +594,32 @@ def pipelined_frames(frames, consume):
     reference does `rgb.cpu().numpy()` + imageio.imwrite between frames, nerf/run.py:199-213, with the GPU idle meanwhile.)
     Order and values are the reference's; CPU tensors pass straight through."""
     pending = None
+    staging = {}                                     # two page-locked staging pairs, reused ping-pong (never one per frame)
 
     def done(item):
         i, h_rgb, h_disp, ev = item
         if ev is not None:
             ev.synchronize()
-        consume(i, h_rgb.numpy(), h_disp.numpy())
+            # hand out PAGEABLE copies: the caller keeps every frame (render_path stacks them at the end) and a 200-frame
+            # 800x800 path would otherwise hold ~2 GB of page-locked memory; the staging pair is free for frame i+2
+            consume(i, np.array(h_rgb.numpy()), np.array(h_disp.numpy()))
+        else:
+            consume(i, h_rgb.numpy(), h_disp.numpy())
 
+    k = 0
     for i, rgb, disp in frames:
         if rgb.is_cuda:
-            h_rgb = torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True)
-            h_disp = torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True)
+            key = (k & 1, tuple(rgb.shape), tuple(disp.shape), rgb.dtype, disp.dtype)
+            if key not in staging:
+                for old_key in [q for q in staging if q[0] == (k & 1)]:
+                    del staging[old_key]             # a path whose frame size changes: drop the slot's old pair
+                staging[key] = (torch.empty(rgb.shape, dtype=rgb.dtype, pin_memory=True), torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True))
+            h_rgb, h_disp = staging[key]
             h_rgb.copy_(rgb.detach(), non_blocking=True)
             h_disp.copy_(disp.detach(), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(rgb.device))
+            k += 1
         else:
             h_rgb, h_disp, ev = rgb.detach(), disp.detach(), None
         if pending is not None:
