@@ -53,11 +53,14 @@ FLOP_PER_ROW_DEFORM = 2 * 497152    # ... through the deformation net (D-NeRF, t
 # Round 4: feature_linear (256 x 256, no activation: model.py:49-53) is folded into views_linears.0 at pack time, so the
 # kernels EXECUTE 65 536 MACs per row fewer than the reference's algorithm.  Every roofline fraction in this file is
 # executed FLOPs / time / peak (it cannot exceed 1); the reference-algorithmic rate rides beside it as algorithmic_tflops.
-FLOP_EXEC_PER_ROW = 2 * (593408 - 65536)
+# ... and the view layer's gamma(d) columns (27 x 128, padded to one 32-slot k-tile = 4096 MACs per row) are a per-RAY constant
+# that the fused passes evaluate once per ray and pass (64 MFMAs = 131 072 MACs) instead of once per row.
+FLOP_EXEC_PER_ROW = 2 * (593408 - 65536 - 4096)
+FLOP_EXEC_PER_RAY_PASS = 2 * 131072
 # training: forward (executed) + dX chain (RGB^T 16 + W_vf^T 128 + 7 x 256 weight steps x 4 MFMAs x 2048 MACs / 32 rows
 # = 495 616 MACs per row: no layer-0 / view-direction input gradients) + dW (the forward's shapes with G = d pre_hv^T h7
 # in place of feature_linear's GEMM = 527 872); the reference-algorithmic figure stays 3 x the forward
-FLOP_EXEC_TRAIN_PER_ROW = 2 * (527872 + 495616 + 527872)
+FLOP_EXEC_TRAIN_PER_ROW = 2 * (523776 + 495616 + 527872)
 FLOP_EXEC_TRAIN_DEFORM_PER_ROW = 2 * (497152 + 7 * 65536 + 497152)        # deformation net: forward + L7..L1 transposed + dW
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md); only used by --precision bf16x3 lines
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
@@ -200,7 +203,7 @@ def build_scene(cfg, dev, rank):
         sc["frame_time"] = 0.5
         sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM)
         sc["flop_per_fine_row"] = FLOP_PER_ROW + FLOP_PER_ROW_DEFORM
-        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM)
+        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM) + 2 * FLOP_EXEC_PER_RAY_PASS
         sc["exec_per_fine_row"] = FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM
         sc["kernel"] = "render_pass_kernel<true>"
     else:
@@ -221,7 +224,7 @@ def build_scene(cfg, dev, rank):
         sc["frame_time"] = None
         sc["flop_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_ROW
         sc["flop_per_fine_row"] = FLOP_PER_ROW
-        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_PER_ROW
+        sc["exec_per_ray"] = (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_PER_ROW + 2 * FLOP_EXEC_PER_RAY_PASS
         sc["exec_per_fine_row"] = FLOP_EXEC_PER_ROW
         sc["kernel"] = "render_pass_kernel<false>"
     sc["K"], sc["c2w"] = synth.lego_camera(sc["H"], sc["W"])
@@ -284,7 +287,7 @@ def extra_configs(dev):
     sd_c, sd_f = (O.to_torch_sd(sd_) for sd_ in st["sds_np"])
     rb1 = O.make_ray_batch(torch.from_numpy(o), torch.from_numpy(d), 2., 6.)
     timeit("C1: 1024 rays x 64 coarse samples, one net", lambda: render.render(400, 400, K4, rays=r1, **kw1), 1024, 64 * FLOP_PER_ROW, 50,
-           ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"], exec_per_ray=64 * FLOP_EXEC_PER_ROW)
+           ref=lambda: O.render_rays(rb1, sd_c, None, N_SAMPLES, 0, white_bkgd=True)["rgb_map"], exec_per_ray=64 * FLOP_EXEC_PER_ROW + FLOP_EXEC_PER_RAY_PASS)
     # the north_star's own target line: lego (nerf/configs/lego.txt: half_res 400x400, N_rand = 1024, 64 + 128, two nets,
     # white_bkgd, use_viewdirs) - 1024 rays are exactly one wave per SIMD on 256 CUs: both launches run a single round
     timeit("north_star: lego 1024-ray batch x (64+128), two nets", lambda: render.render(400, 400, K4, rays=r1, **kw), 1024, st["flop_per_ray"], 50,
@@ -398,7 +401,7 @@ def extra_configs(dev):
         opt.step()
     torch.cuda.reset_peak_memory_stats(dev)
     timeit("training step: 4096 rays x (64+128), two nets, mse(rgb)+mse(rgb0), backward, Adam (3x forward FLOPs)", train_step,
-           N_RAND, 3 * st["flop_per_ray"], 5, grad=True, exec_per_ray=(N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_TRAIN_PER_ROW)
+           N_RAND, 3 * st["flop_per_ray"], 5, grad=True, exec_per_ray=(N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_EXEC_TRAIN_PER_ROW + 2 * FLOP_EXEC_PER_RAY_PASS)
     rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     for m in nets:
         m.eval()
@@ -448,7 +451,7 @@ def extra_configs(dev):
     torch.cuda.reset_peak_memory_stats(dev)
     timeit("D-NeRF training step: 4096 rays x (64+128), one DirectTemporalNeRF at t=0.5, mse(rgb), backward, Adam", train_step_dnerf,
            N_RAND, (N_SAMPLES + 3 * (N_SAMPLES + N_IMPORTANCE)) * (FLOP_PER_ROW + FLOP_PER_ROW_DEFORM), 4, grad=True,
-           exec_per_ray=N_SAMPLES * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM)
+           exec_per_ray=N_SAMPLES * (FLOP_EXEC_PER_ROW + FLOP_PER_ROW_DEFORM) + 2 * FLOP_EXEC_PER_RAY_PASS
            + (N_SAMPLES + N_IMPORTANCE) * (FLOP_EXEC_TRAIN_PER_ROW + 2 * 32768 + FLOP_EXEC_TRAIN_DEFORM_PER_ROW))   # + the 128 d gamma(x+dx) steps
     rows[-1]["peak_mem_gib"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     dn.eval()
@@ -625,7 +628,7 @@ def worker(args):
     fine_ms = float(np.mean(ms_kernel)) if ms_kernel else float("nan")
     if train:
         args.no_cpu_baseline = args.no_extra = True
-    fine_flop = n_local * S_FINE * sc["exec_per_fine_row"]              # MFMA FLOPs the launch EXECUTES (feature_linear folded)
+    fine_flop = n_local * (S_FINE * sc["exec_per_fine_row"] + FLOP_EXEC_PER_RAY_PASS)   # MFMA FLOPs the launch EXECUTES (fold + per-ray gamma(d))
     fine_flop_alg = n_local * S_FINE * sc["flop_per_fine_row"]          # ... the reference's algorithm would
     achieved = fine_flop / (fine_ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
@@ -668,10 +671,11 @@ def worker(args):
                      "kernel": f"{sc['kernel']} fine pass ({n_local} rays x {S_FINE} samples)" + (", TRAIN forward variant" if train else ""),
                      "ms_per_launch": fine_ms, "flop_per_launch": fine_flop,
                      "flop_accounting": "executed: feature_linear (65 536 MACs/row, no activation) is folded into views_linears.0 at pack "
-                                        "time, 527 872 MACs/row run (+497 152 for the deformation net); algorithmic_* = the reference's 593 408",
+                                        "time and the view layer's gamma(d) columns are evaluated once per ray (131 072 MACs) instead of per "
+                                        "row: 523 776 MACs/row run (+497 152 for the deformation net); algorithmic_* = the reference's 593 408",
                      "algorithmic_flop_per_launch": fine_flop_alg, "algorithmic_tflops": fine_flop_alg / (fine_ms * 1e-3) / 1e12,
-                     "step_frac": rays_per_step / world * (S_FINE + N_SAMPLES) * (FLOP_EXEC_TRAIN_PER_ROW if train else sc["exec_per_fine_row"])
-                                  / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                     "step_frac": rays_per_step / world * ((S_FINE + N_SAMPLES) * (FLOP_EXEC_TRAIN_PER_ROW if train else sc["exec_per_fine_row"])
+                                                           + 2 * FLOP_EXEC_PER_RAY_PASS) / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
     }
     if x3:
         # the fine pass runs 3 bf16 MFMAs per product: price the matrix work it really does against the dense bf16 peak

@@ -100,6 +100,17 @@ __device__ __forceinline__ void ws_rewind(WStream& ws, const float* w, const flo
     ws.bias = lds_bias + (lane >> 5) * 16;
 }
 
+// Leave the stream the ring was following and continue at `w` (a stream whose head the ring does NOT hold): drain what is in
+// flight, prime the ring afresh.  One exposed L2 round trip - for the kernels that evaluate one tile per wave (mlp_forward, the
+// point query's entry into its views loop), never inside the fused passes' tile loop.
+__device__ __forceinline__ void ws_restart(WStream& ws, const float* w) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ws.base = reinterpret_cast<const char*>(w);
+    ws_prime<0>(ws);
+    ws_wait<SW_RING - 1>();
+    ws.a_cur = ws_read(ws, 0);
+}
+
 enum { SEG_ACC = 0, SEG_BIAS = 1, SEG_ZERO = 2, SEG_BIAS_SCALED = 3 };
 // accumulator-init values of output tile n (bias tile n of the segment) for this lane half
 template <int INIT>
@@ -455,16 +466,42 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
 // ---- canonical tail: [feature_linear folded into] views_linears[0] + relu -> rgb_linear ---
 // `in` = relu(layer 7).  On return rgb[0..2] = raw rgb of row j on every lane (model.py:49-58).
 // feature_linear has no activation, so the packed stream carries W_vf = Wv[:, :256] . W_f and b_vf = Wv[:, :256] . b_f + b_v
-// (swnerf_common.h SW_CANON_STEPS, pack_kernels.hip fold_views_kernel): ONE 4 x 9 segment on [h7 | gamma(d)].
+// (swnerf_common.h SW_CANON_STEPS, pack_kernels.hip fold_views_kernel).
 // hb_rgb: the head-bias tile (LDS) saved by the caller: [b_alpha, b_r, b_g, b_b].
-// demb: the view-direction k-tile (pe_dir), supplied by the caller.
-__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], const f32x16& demb, float (&rgb)[3], const float* hb_rgb, WStream& ws) {
-    f32x16 k9[9];
+//
+// Two forms of the view layer:
+//  * canon_tail_rows: directions vary per ROW (mlp_forward on embedded rows, the point query): one 4 x 9 segment on
+//    [gamma(d) | h7] taken from the blob's views-loop stream (ws_restart), initialised from the b_vf tiles;
+//  * canon_tail / canon_tail_train: the fused passes, ONE direction per ray: the wave has evaluated
+//    c = Wv[:, 256:] gamma(d) + b_vf once (view_bias_tile below: 64 MFMAs per RAY) and every tile runs a 4 x 8 segment on h7
+//    whose accumulators start from c - 64 MFMAs per TILE less.
+#define SW_VB_LDS_FLOATS (4 * SW_BIAS_TILE_FLOATS)       // per wave: the per-ray init tiles of the view layer, [n][h][r]
+
+// once per ray, right after ws_start on a stream that begins with the DIR prefix: vb[n][h][r] = c[32n + frow(r,h)]
+__device__ __forceinline__ void view_bias_tile(const f32x16& demb, float* lds_vb, int lane, WStream& ws) {
+    f32x16 k1[1], c[4];
+    k1[0] = demb;
+    seg_mfma<4, 1, SEG_BIAS>(c, k1, ws);                     // every column j of the result is the same: gamma(d) is the ray's
+    if ((lane & 31) == 0) {
+        float* o = lds_vb + (lane >> 5) * 16;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = in[n];
-    k9[8] = demb;                                           // cat[h7, input_views]
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {c[n][4 * g], c[n][4 * g + 1], c[n][4 * g + 2], c[n][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(o + n * SW_BIAS_TILE_FLOATS + 4 * g) = v;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], const float* lds_vb, float (&rgb)[3], const float* hb_rgb, WStream& ws) {
     f32x16 hv[4];
-    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
+    const float* keep = ws.bias;
+    ws.bias = lds_vb + (threadIdx.x & 32 ? 16 : 0);
+    seg_mfma<4, 8, SEG_BIAS>(hv, in, ws);
+    ws.bias = keep;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -476,14 +513,13 @@ __device__ __forceinline__ void canon_tail(const f32x16 (&in)[8], const f32x16& 
 // The same tail in the fused training passes: h7 (`in`, ReLU mask `mb`) is side-stored by the view layer's segment, whose B
 // operand it is; the view hidden layer and its mask are stored on the spot (act_row / mask_tile: trunk_pass).  `feature` does
 // not exist: the weight gradients on both sides of feature_linear follow from G = d pre_hv^T . h7 (swnerf_feature_finish).
-__device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], const f32x16& demb, float (&rgb)[3], const float* hb_rgb,
+__device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], const float* lds_vb, float (&rgb)[3], const float* hb_rgb,
                                                  WStream& ws, float* act_row, float* mask_tile, const f32x4& mb) {
-    f32x16 k9[9];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = in[n];
-    k9[8] = demb;
     f32x16 hv[4];
-    seg_mfma<4, 9, SEG_BIAS, 8>(hv, k9, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
+    const float* keep = ws.bias;
+    ws.bias = lds_vb + (threadIdx.x & 32 ? 16 : 0);
+    seg_mfma<4, 8, SEG_BIAS, 8>(hv, in, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
+    ws.bias = keep;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -492,4 +528,24 @@ __device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], const f3
     *reinterpret_cast<f32x4*>(mask_tile + 256 * 8) = relu_bits<4>(hv);
     head_valu<3, 4>(hv, ws, rgb);
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];
+}
+
+// Per-row directions: the 4 x 9 view layer from the views-loop stream, whose k-tile order is [gamma(d) | h7] - the accumulators
+// take b_vf, then the direction terms, then the h7 terms: EXACTLY the sequence of view_bias_tile + canon_tail, so the op path and
+// the fused pass produce the same bits (the resampling downstream is a discontinuous function of the coarse weights: two paths of
+// one library must not differ in the last bit there).  The caller has put the ring onto `wvl` (ws_restart, or a
+// previous turn whose tail is the stream's own head) and ws.base = wvl; bvf: the b_vf tiles (LDS, + 16 h).
+__device__ __forceinline__ void canon_tail_rows(const f32x16 (&in)[8], const f32x16& demb, f32x16 (&hv)[4], const float* bvf, WStream& ws) {
+    f32x16 k9[9];
+    k9[0] = demb;                                           // cat[h7, input_views], direction k-tile first
+#pragma unroll
+    for (int n = 0; n < 8; ++n) k9[1 + n] = in[n];
+    const float* keep = ws.bias;
+    ws.bias = bvf;
+    seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
+    ws.bias = keep;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
 }

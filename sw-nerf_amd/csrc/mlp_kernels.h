@@ -10,7 +10,7 @@
 
 #define SW_LDS_BIAS_FLOATS ((SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)
 #define SW_ZSLOT_FLOATS 128          // per wave: two 64-float slots for the next tile's depths (fine pass)
-#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS)   // per wave: weight ring + parked embedding + depths
+#define SW_LDS_RING_FLOATS (SW_RING * SW_STEP_FLOATS + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS + SW_VB_LDS_FLOATS)   // per wave: weight ring + parked embedding + depths + per-ray view-layer init tiles
 #define SW_LDS_FIXED_FLOATS (SW_LDS_BIAS_FLOATS + 4 * SW_LDS_RING_FLOATS)
 
 // ------------------------------------------------------------------------------------------
@@ -20,7 +20,8 @@ struct MlpDev {
     const float* x; int64_t M; int C;   // C = C_pos + C_dir
     int Lp, Ld, Lt, Cpos;
     const float* t_emb; int Ct;
-    const float* w0; const float* b0; int nbias; int two_pass;
+    const float* w0; const float* b0; int nbias; int two_pass;     // w0: the stream as stream_ptrs gives it (DIR prefix first)
+    const float* wvl;       // the blob's views-loop stream: the 4 x 9 view layer on [h7 | gamma(d)] (directions vary per row here)
     float* out; float* dx;
     float* act;             // TRAIN: [M, SW_ACT_LD] activations saved for the backward pass
     float* bits;            // TRAIN: [ceil(M/32), SW_MASK_TILE_FLOATS] ReLU bit masks (mlp_core.h relu_bits)
@@ -51,7 +52,8 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
     float* mask_tile = TRAIN ? P.bits + tile * SW_MASK_TILE_FLOATS + lane * 4 : nullptr;
     f32x4 mb = {0.f, 0.f, 0.f, 0.f};
     WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    // per-row directions: skip the per-ray DIR prefix of the stream (and its b_vf tiles), take the view layer from the views loop
+    ws_start(ws, P.w0 + SW_STEPS_DIR * SW_STEP_FLOATS, lds_bias + SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS, lds_ring, lane);
     float ex = 0.f, ey = 0.f, ez = 0.f;
     if (DNERF) {
         const float ft = P.t_emb ? P.t_emb[(live ? row : P.M - 1) * P.Ct] : 0.f;   // column 0 of gamma(t) is t
@@ -67,24 +69,20 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpDev P) {
         trunk_pass<false, TRAIN>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb);
     }
     // views_linears[0] on cat[feature, input_views] with feature_linear folded in (swnerf_common.h SW_CANON_STEPS): one
-    // segment on [h7 | gamma(d)]; the view-direction features are gathered like the position ones.  TRAIN: h7 and its mask
-    // leave as side stores of this segment.
+    // segment on [gamma(d) | h7] from the views-loop stream; the view-direction features are gathered like the position ones.
     const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
-    f32x16 k9[9];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) k9[n] = in[n];
+    f32x16 demb, hv[4];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const int col = sw_dir_col(a, h, P.Ld);
-        k9[8][a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
+        demb[a] = (col >= 0) ? xr[P.Cpos + col] : 0.f;
     }
-    f32x16 hv[4];
-    if (TRAIN) seg_mfma<4, 9, SEG_BIAS, TRAIN ? 8 : 0>(hv, k9, ws, 1.f, SideStore{act_row + 256 * 7, mask_tile + 256 * 7, mb});
-    else seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
+    if (TRAIN) {                                              // h7 and its mask: stored on the spot (op path; the fused passes side-store)
+        tiles_store<8>(act_row + 256 * 7, in);
+        *reinterpret_cast<f32x4*>(mask_tile + 256 * 7) = mb;
+    }
+    ws_restart(ws, P.wvl);
+    canon_tail_rows(in, demb, hv, lds_bias + h * 16, ws);
     if (TRAIN) {
         tiles_store<4>(act_row + SW_ACT_HV, hv);
         *reinterpret_cast<f32x4*>(mask_tile + 256 * 8) = relu_bits<4>(hv);
@@ -110,6 +108,11 @@ static inline int stream_ptrs(int kind, const float* packed, int run_deform, con
         return sw_fail(SWNERF_E_ARG, "unknown net kind %d", kind);
     }
     return 0;
+}
+
+// the views-loop stream of a blob (the 4 x 9 view layer on [h7 | gamma(d)] for per-row directions): in its (last) CANON blob
+static inline const float* views_loop_ptr(int kind, const float* packed) {
+    return packed + (kind == SWNERF_NET_DNERF ? SW_DNERF_A_FLOATS : 0) + SW_CANON_VL_OFFSET;
 }
 
 // SWNERF_NET_NOVIEW: stream and bias tiles of the net without view directions (swnerf_pack_net_noview)

@@ -244,13 +244,21 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     float* fold = packed + (kind == SWNERF_NET_DNERF ? SW_DNERF_A_FLOATS : 0) + SW_CANON_FOLD_OFFSET;
     int rc = fold_views(params, Cdir, fold, st);
     if (rc) return rc;
+    int b8[8];
+    for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
+    // DIR: the gamma(d) columns of the folded view layer + b_vf, evaluated once per ray by the fused passes (swnerf_common.h)
+    auto dir = [&](Packer& pk) {
+        pk.seg(fold, fold + 128 * SW_FOLD_LD, 128, SW_FOLD_LD, 4, 1, vt + 8, vb + 8);
+        pk.have_head = false;                                                      // the ring tail repeats the head of MAIN, not DIR
+    };
     auto canon = [&](Packer& pk) {
         pk.trunk(params, params[20], params[21], 1, Cpos, 0, params[23], 3);       // ... alpha_linear + head biases
-        pk.seg(fold, fold + 128 * SW_FOLD_LD, 128, SW_FOLD_LD, 4, 9, vt, vb);      // VIEWSF on [h7 | gamma(d)]
+        pk.seg(fold, nullptr, 128, SW_FOLD_LD, 4, 8, vt, b8);                      // VIEWSH on h7 (accumulators start from the per-ray tile)
         pk.vecs(params[22], 3, 128);                                               // rgb_linear.weight
     };
     if (kind == SWNERF_NET_DNERF) {
         Packer pk(st, packed, packed + SW_DNERF_W_FLOATS, L_pos, L_dir, L_time);
+        dir(pk);
         pk.trunk(params + 24, params[40], params[41], 3, Cpos, Ctime);             // deformation net
         canon(pk);
         if (!pk.rc && pk.w != packed + (size_t)(SW_DEFORM_STEPS + SW_CANON_STEPS) * SW_STEP_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
@@ -259,6 +267,7 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
         packed += SW_DNERF_A_FLOATS;                                               // then the canon-only blob
     }
     Packer pk(st, packed, packed + SW_CANON_W_FLOATS, L_pos, L_dir, L_time);
+    dir(pk);
     canon(pk);
     if (!pk.rc && (pk.w != packed + (size_t)SW_CANON_STEPS * SW_STEP_FLOATS || pk.b != packed + SW_CANON_VL_OFFSET))
         return sw_fail(SWNERF_E_ARG, "pack_net: internal layout mismatch");
@@ -266,7 +275,10 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     if ((rc = pk.flush())) return rc;
     // the view branch once more, as a stream that wraps onto itself (biases: the tiles packed above)
     Packer vl(st, packed + SW_CANON_VL_OFFSET, nullptr, L_pos, L_dir, L_time);
-    vl.seg(fold, nullptr, 128, SW_FOLD_LD, 4, 9, vt, vb);
+    int vt2[9], vb2[9];                                                          // k-tile order [gamma(d) | h7]: the summation order of
+    vt2[0] = KT_DIR; vb2[0] = 256;                                                // DIR + VIEWSH (mlp_core.h canon_tail_rows)
+    for (int i = 0; i < 8; ++i) { vt2[1 + i] = KT_TRUNK; vb2[1 + i] = 32 * i; }
+    vl.seg(fold, nullptr, 128, SW_FOLD_LD, 4, 9, vt2, vb2);
     vl.tail();
     return vl.flush();
 }

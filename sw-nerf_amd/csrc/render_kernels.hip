@@ -41,32 +41,27 @@ __global__ void __launch_bounds__(256, 1) query_points_kernel(QueryDev P) {
     float head[3];
     pe_pos(P.pts[rr * 3], P.pts[rr * 3 + 1], P.pts[rr * 3 + 2], h, emb);
     WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    // directions vary per point / per loop turn: skip the stream's per-ray DIR prefix (and its b_vf tiles)
+    ws_start(ws, P.w0 + SW_STEPS_DIR * SW_STEP_FLOATS, lds_bias + SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS, lds_ring, lane);
     trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
     const float* hb_rgb = ws.bias - SW_BIAS_TILE_FLOATS;      // [b_alpha, b_r, b_g, b_b]
-    // feature_linear is folded into the view layer (swnerf_common.h SW_CANON_STEPS): the loop below runs on [h7 | gamma(d)].
-    // The ring now holds the first VIEWSF steps; the views-loop region starts with the same ones
-    ws.base = reinterpret_cast<const char*>(P.wvl);
+    const float* rgb_tiles = ws.bias;                         // rgb_linear.weight as bias-style tiles: re-read on every turn
+    // feature_linear is folded into the view layer (swnerf_common.h SW_CANON_STEPS): the loop below runs the 4 x 9 segment on
+    // [gamma(d) | h7] from the views-loop stream, whose tail is its own head.
+    ws_restart(ws, P.wvl);
     float sr = 0.f, sg = 0.f, sb = 0.f;
     const int64_t nv = P.shared ? P.V : 1;
 #pragma nounroll
     for (int64_t v = 0; v < nv; ++v) {
         const float* dp = P.dirs + (P.shared ? v : rr) * 3;
-        f32x16 k9[9];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) k9[n] = in[n];
-        pe_dir(dp[0], dp[1], dp[2], h, k9[8]);
-        ws.bias = lds_bias + SW_CANON_BIAS_TILE_VIEWS * SW_BIAS_TILE_FLOATS + h * 16;
-        f32x16 hv[4];
-        seg_mfma<4, 9, SEG_BIAS>(hv, k9, ws);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
+        f32x16 demb, hv[4];
+        pe_dir(dp[0], dp[1], dp[2], h, demb);
+        ws.bias = rgb_tiles;
+        ws.base = reinterpret_cast<const char*>(P.wvl);
+        canon_tail_rows(in, demb, hv, lds_bias + h * 16, ws);
         float c3[3];
         head_valu<3, 4>(hv, ws, c3);
         sr += c3[0] + hb_rgb[1]; sg += c3[1] + hb_rgb[2]; sb += c3[2] + hb_rgb[3];
-        ws.base = reinterpret_cast<const char*>(P.wvl);      // the region's tail is its own head
     }
     if (live && h == 0) {
         const float inv = 1.f / (float)nv;
@@ -94,6 +89,7 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
                     : stream_ptrs(a.kind, a.packed, a.run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
     P.sort_n = 0; P.sort_s = 0;
+    P.dir_steps = noview ? 0 : SW_STEPS_DIR;
     size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine && a.n_rays != 0) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
@@ -185,6 +181,7 @@ extern "C" int swnerf_mlp_forward(int kind, const float* packed, const float* x,
     P.out = out; P.dx = dx_out; P.act = nullptr; P.bits = nullptr;
     int rc = stream_ptrs(kind, packed, run_deform, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
+    P.wvl = views_loop_ptr(kind, packed);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((M + 127) / 128)), block(256);
     const size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);

@@ -35,6 +35,7 @@ struct PassDev {
     float* act_d; float* bits_d; float* xs_d;
     // start-up shaping of a launch (fp32 inference pass; pass_startup() below): L2 warm-up of the weight stream and a skew
     // of the waves' start.  warm_steps = 0 / skew_mode = 0 switch them off.
+    int dir_steps;          // SW_STEPS_DIR when the stream starts with the per-ray DIR prefix (nets with view directions, fp32), else 0
     int warm_steps;         // 1-KiB steps of the weight stream to pull into the XCD's L2 at kernel start
     int warm_blocks;        // workgroups per XCD that share the warm-up (blocks b with b < 8 * warm_blocks take part)
     int skew_mode;          // 0 none | 1 per workgroup | 2 per wave
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     float* lds_emb = lds_ring + SW_RING * SW_STEP_FLOATS;
     float* lds_x3w = lds_ring + X3_RING_FLOATS + wv * X3Lds<DNERF>::WAVE;
     float* lds_dir = PREC ? lds_x3w : lds_emb + 2 * 16 * 64;
+    float* lds_vb = lds_emb + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS;          // fp32, VIEWS: the per-ray init tiles of the view layer
     float* lds = PREC ? lds_all + X3Lds<DNERF>::FIXED + wv * SW_LDS_WAVE_FLOATS
                       : lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
@@ -185,9 +187,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         // view-direction encoding is parked where the junk went; its ~300 VALU cycles run while steps 1..7 are in flight
         ws_start(ws, P.w0, lds_bias, lds_ring, lane);
         if constexpr (VIEWS) {
+            // the stream's DIR prefix, once per ray: c = Wv[:, 256:] gamma(d) + b_vf -> the view layer's init tiles (mlp_core.h)
             f32x16 demb;
             pe_dir(v0, v1, v2, h, demb);
-            tile_park(lds_dir, lane, demb);
+            if constexpr (TRAIN) tile_park(lds_dir, lane, demb);             // the training passes also store gamma(d) per row (xs)
+            view_bias_tile(demb, lds_vb, lane, ws);
         }
     }
 
@@ -265,8 +269,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                     }
                 }
             }
-            tile_fetch(lds_dir, lane, demb);
-            canon_tail_train(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+            canon_tail_train(in, lds_vb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if (DNERF && PREC != 0) {
             if constexpr (DNERF && PREC != 0) {
 #pragma nounroll
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
                 *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
             }
             trunk_pass<false, true, true>(emb, lds_emb, 0.f, false, h, in, out, head, ws, act_row, mask_tile, false, &mb, xs_row);
-            canon_tail_train(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
+            canon_tail_train(in, lds_vb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws, act_row, mask_tile, mb);
         } else if constexpr (PREC != 0) {
             head[1] = 0.f; head[2] = 0.f;
 #ifdef X3_NO_PIPE                                   // the plain form (split phase between layers): experiments / reference
@@ -363,13 +366,10 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             trunk_pass<false>(emb, lds_emb, 0.f, false, h, in, out, head, ws);
         }
         SW_STAMP(pt2);
-        if (!TRAIN && PREC == 0 && VIEWS) {
-            f32x16 demb;
-            tile_fetch(lds_dir, lane, demb);
-            canon_tail(in, demb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
-        }
+        if (!TRAIN && PREC == 0 && VIEWS) canon_tail(in, lds_vb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
         SW_STAMP(pt3);
-        if constexpr (PREC == 0) ws_rewind(ws, P.w0, lds_bias, lane);
+        // back to the head of MAIN (behind the per-ray DIR prefix and its b_vf tiles)
+        if constexpr (PREC == 0) ws_rewind(ws, P.w0 + P.dir_steps * SW_STEP_FLOATS, lds_bias + (P.dir_steps ? SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS : 0), lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
         const float c0 = rgb[0], c1 = rgb[1], c2 = rgb[2];

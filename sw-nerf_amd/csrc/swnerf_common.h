@@ -24,7 +24,9 @@
 #define SW_STEPS_EMB    64        // 8 n-tiles x 2 pos-emb k-tiles
 #define SW_STEPS_EMB_T  96        // 8 x 3 (pos emb + time emb): deformation layer 0
 #define SW_STEPS_TRUNK  256       // 8 x 8
-#define SW_STEPS_VIEWS  144       // 4 x 9   (feature 8 tiles + dir emb 1 tile)
+#define SW_STEPS_VIEWS  144       // 4 x 9   [h7 | gamma(d)]: the view layer where directions vary per ROW (mlp_forward, point query)
+#define SW_STEPS_DIR    16        // 4 x 1   gamma(d) alone: ONCE PER RAY in the fused passes (below)
+#define SW_STEPS_VIEWSH 128       // 4 x 8   h7 alone: the view layer of the fused passes, initialised from the per-ray tile
 // The 1- and 3-output heads (alpha_linear, rgb_linear, _time_out) are NOT in the MFMA stream: a 32-wide
 // padded tile would spend 128 / 64 MFMAs on 1 / 3 useful rows.  They are VALU dot products over the
 // features a lane already holds (mlp_core.h head_valu); their weights sit with the biases in LDS.
@@ -36,13 +38,20 @@
 // - ONE 4 x 9 segment on [h7 | gamma(d)] instead of an 8 x 8 and a 4 x 9 one: 8256 MFMAs per tile instead of 9280.  The
 // pack kernel forms W_vf / b_vf with double accumulation and one rounding (pack_kernels.hip fold_views_kernel); module
 // parameters, checkpoints and the weight-gradient algebra (G-based: swnerf_feature_finish) are untouched.
-#define SW_CANON_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
-                        2 * SW_STEPS_TRUNK + SW_STEPS_VIEWS)
+// The view-direction columns of the view layer are a per-RAY constant (one direction per ray, nerf/run.py:80-82 expands it over the
+// samples): the fused passes evaluate  c = Wv[:, 256:] gamma(d) + b_vf  ONCE per ray (the DIR prefix of the stream: 64 MFMAs), keep
+// it in a per-wave LDS tile and start every tile's view-layer accumulators from it - 8192 MFMAs per tile instead of 8256.
+//   stream: DIR | MAIN = L0 | L1..L4 | L5(trunk) L5(emb) | L6 L7 | VIEWSH ;  ring tail = copy of MAIN's first SW_TAIL steps
+//   (a tile rewinds to MAIN; kernels whose directions vary per row skip DIR and take the 4 x 9 view layer from the views loop)
+#define SW_CANON_MAIN_STEPS (SW_STEPS_EMB + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + \
+                             2 * SW_STEPS_TRUNK + SW_STEPS_VIEWSH)
+#define SW_CANON_STEPS (SW_STEPS_DIR + SW_CANON_MAIN_STEPS)
 // "bias" tiles of 32 floats ([h][r], the accumulator-init layout) in consumption order:
-//   L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8, then 1 tile of head biases (alpha, r, g, b) |
-//   VIEWSF 4 (b_vf) | rgb_linear.weight 3 x 4
-#define SW_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 4 + 12)
-#define SW_CANON_BIAS_TILE_VIEWS (8 + 32 + 8 + 16 + 8 + 1)   // index of the first views_linears bias tile
+//   b_vf 4 (consumed by DIR, once per ray; also the init tiles of the 4 x 9 view layer) |
+//   L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8, then 1 tile of head biases (alpha, r, g, b) | rgb_linear.weight 3 x 4
+#define SW_CANON_BIAS_TILES (4 + 8 + 32 + 8 + 16 + 8 + 1 + 12)
+#define SW_DIR_BIAS_TILES 4
+#define SW_CANON_BIAS_TILE_VIEWS 0                            // index of the first views_linears (b_vf) bias tile
 // the folded matrix itself rides at the end of a CANON blob: [128][SW_FOLD_LD] = [W_vf | Wv[:, 256:]] then b_vf[128]
 #define SW_FOLD_LD 288
 #define SW_FOLD_FLOATS (128 * SW_FOLD_LD + 128)
@@ -59,7 +68,7 @@
 #define SW_NOVIEW_W_FLOATS ((SW_NOVIEW_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_NOVIEW_FLOATS (SW_NOVIEW_W_FLOATS + SW_NOVIEW_BIAS_TILES(SW_NOVIEW_MAX_OUT) * SW_BIAS_TILE_FLOATS)
 
-// blob CANON : [canon steps][ring tail = copy of first SW_TAIL steps][canon bias][views loop][fold scratch]
+// blob CANON : [DIR][canon MAIN steps][ring tail = copy of MAIN's first SW_TAIL steps][b_vf | canon bias][views loop][fold scratch]
 // views loop  : [VIEWS steps][tail = copy of the first SW_TAIL VIEWS steps] - the view
 //               branch as a stream that wraps onto itself, for queries of many view directions per
 //               point (swnerf_query_points: trunk and density once, view branch V times)
@@ -68,7 +77,7 @@
 #define SW_CANON_VL_FLOATS  ((SW_STEPS_VIEWS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_CANON_FOLD_OFFSET (SW_CANON_VL_OFFSET + SW_CANON_VL_FLOATS)
 #define SW_CANON_FLOATS     (SW_CANON_FOLD_OFFSET + SW_FOLD_FLOATS)
-// blob DNERF : [deform steps][canon steps][ring tail][deform bias][canon bias] then a full CANON blob
+// blob DNERF : [DIR][deform steps][canon MAIN steps][ring tail = head of deform][b_vf | deform bias | canon bias] then a full CANON blob
 // (the CANON blob serves the `t==0 and zero_canonical` branch, model.py:143-145)
 #define SW_DNERF_W_FLOATS   ((SW_DEFORM_STEPS + SW_CANON_STEPS + SW_TAIL) * SW_STEP_FLOATS)
 #define SW_DNERF_A_FLOATS   (SW_DNERF_W_FLOATS + (SW_DEFORM_BIAS_TILES + SW_CANON_BIAS_TILES) * SW_BIAS_TILE_FLOATS)

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256, 1) deform_forward_train_kernel(DeformDev 
     }
     const float ft = P.t_emb[rr * P.Ct];                                  // column 0 of gamma(t) is t
     WStream ws;
-    ws_start(ws, P.w0, lds_bias, lds_ring, lane);
+    ws_start(ws, P.w0 + SW_STEPS_DIR * SW_STEP_FLOATS, lds_bias + SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS, lds_ring, lane);   // (behind the per-ray DIR prefix)
     trunk_pass<true, true>(emb, lds_emb, ft, true, h, in, out, head, ws, P.act + rr * SW_ACT_LD + 4 * h,
                            P.bits + tile * SW_MASK_TILE_FLOATS + lane * 4, true, nullptr);
     if (live && h == 0) { P.dx[row * 3] = head[0]; P.dx[row * 3 + 1] = head[1]; P.dx[row * 3 + 2] = head[2]; }
@@ -531,6 +531,7 @@ extern "C" int swnerf_mlp_forward_train(const float* packed, const float* x, int
     P.t_emb = nullptr; P.Ct = 1; P.out = out; P.dx = nullptr; P.act = act; P.bits = bits;
     int rc = stream_ptrs(SWNERF_NET_CANON, packed, 0, &P.w0, &P.b0, &P.nbias, &P.two_pass);
     if (rc) return rc;
+    P.wvl = views_loop_ptr(SWNERF_NET_CANON, packed);
     const dim3 grid((unsigned)((M + 127) / 128)), block(256);
     hipLaunchKernelGGL((mlp_forward_kernel<false, true>), grid, block, SW_LDS_FIXED_FLOATS * sizeof(float), (hipStream_t)stream, P);
     return sw_check(hipGetLastError(), "mlp_forward_train launch");
@@ -577,6 +578,7 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     if (rc) return rc;
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = nullptr; P.bits_d = nullptr; P.xs_d = nullptr;
     P.sort_n = 0; P.sort_s = 0;
+    P.dir_steps = noview ? 0 : SW_STEPS_DIR;
     P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     size_t lds = PassLds<false, true>::FIXED * sizeof(float);
     if (a.n_importance > 0) {
@@ -663,6 +665,7 @@ extern "C" int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args, floa
     if (rc) return rc;
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = act_d; P.bits_d = bits_d; P.xs_d = xs_d;
     P.sort_n = 0; P.sort_s = 0;
+    P.dir_steps = SW_STEPS_DIR;
     P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     const size_t lds = PassLds<true, true>::FIXED * sizeof(float);
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);

@@ -124,7 +124,8 @@ extern "C" int swnerf_pack_net_x3_kind(int kind, const float* const* params, int
             return sw_fail(SWNERF_E_ARG, "pack_net_x3: internal layout mismatch");
         if ((rc = copy(reinterpret_cast<float*>(pk.w), packed_x3, (size_t)SW_X3_TAIL_CHUNKS * SW_X3_CHUNK_FLOATS, "pack_net_x3 tail copy"))) return rc;
         // bias tiles: the deformation net's as in the fp32 blob, the canonical net's in the unfolded order (this core runs feature_linear)
-        if ((rc = copy(packed_x3 + SW_X3_DNERF_W_FLOATS, packed_fp32 + SW_DNERF_W_FLOATS,
+        // (the fp32 blob's bias stream starts with the 4 b_vf tiles of its per-ray DIR prefix; the deformation net's follow)
+        if ((rc = copy(packed_x3 + SW_X3_DNERF_W_FLOATS, packed_fp32 + SW_DNERF_W_FLOATS + SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS,
                        (size_t)SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, "pack_net_x3 bias copy"))) return rc;
         if ((rc = sw_pack_canon_bias_unfolded(params, packed_x3 + SW_X3_DNERF_W_FLOATS + SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, st))) return rc;
         packed_x3 += SW_X3_DNERF_A_FLOATS;                                          // then the canon-only blob (t == 0 branch)

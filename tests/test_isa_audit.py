@@ -42,9 +42,11 @@ def test_mfma_kernels_isa(asm):
         assert not bad, f"{name}: {len(bad)} uses of in-flight asm-load registers, e.g. {bad[0]}"
         dma = len(re.findall(r"global_load_lds_dwordx4", body))
         seen[name] = (stats, dma)
-        # code is unrolled per segment type: L0(64) trunk(256) skip-emb(64) views(144) - feature_linear is folded into the
-        # view layer at pack time (swnerf_common.h SW_CANON_STEPS: 8256 MFMAs per tile instead of 9280), so NO 256-step
-        # feature body may be left - (+ the 96-step deformation layer 0 in the D-NeRF instantiations); +8 priming DMAs
+        # code is unrolled per segment type: L0(64) trunk(256) skip-emb(64) and the view layer - feature_linear is folded into
+        # it at pack time (swnerf_common.h SW_CANON_STEPS), so NO 256-step feature body may be left.  The fused passes run the view
+        # layer as DIR (16 steps, once per RAY: outside the tile loop) + VIEWSH (128 per tile): 8192 MFMAs per tile instead of
+        # round 3's 9280; kernels with per-row directions run one 144-step [gamma(d) | h7] segment.  Same static count either way.
+        # (+ the 96-step deformation layer 0 in the D-NeRF instantiations); +8 priming DMAs
         steps = 64 + 256 + 64 + 144 + (96 if "kernelILb1" in name else 0)
         if "query_points" in name:
             steps = 64 + 256 + 64 + 144
@@ -77,7 +79,10 @@ def test_mfma_kernels_isa(asm):
                                            "render_pass_kernelILb0ELb1E", "render_pass_kernelILb1ELb1E"))
         # the fused pass pulls the weight stream into L2 at kernel start with one more static DMA site (render_pass.h pass_startup)
         warm = 1 if "render_pass_kernel" in name else 0
-        assert dma == steps + (16 if training else 8) + masks + warm, (name, dma)
+        # kernels whose view directions vary per row leave the main stream behind the trunk and prime the ring afresh on the views
+        # loop (mlp_core.h ws_restart): one more set of priming DMAs
+        restart = (16 if training else 8) if ("query_points" in name or "mlp_forward_kernel" in name) else 0
+        assert dma == steps + (16 if training else 8) + masks + warm + restart, (name, dma)
     assert len(seen) == 18
     for name in seen:
         m = re.search(rf"\.amdhsa_kernel {name}.*?\.end_amdhsa_kernel", asm, re.S)

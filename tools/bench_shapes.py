@@ -20,7 +20,7 @@ if what == "north_star":
     embeddirs_fn, in_views = embedder.get_embedder(4, 3, 0)
     specs = [(synth.nerf_state_dict(s, alpha_bias=ab), dict(input_ch_views=in_views, use_viewdirs=True)) for s, ab in (synth.NET_COARSE, synth.NET_FINE)]
     H = W = 400
-    N, flop_row, use_views = 1024, 2 * (593408 - 65536), True       # EXECUTED MACs: feature_linear is folded into the view layer
+    N, flop_row, use_views = 1024, 2 * (593408 - 65536 - 4096) + 2 * 2 * 131072 / 256, True       # EXECUTED MACs per row: feature_linear folded, gamma(d) once per ray and pass
 else:
     embeddirs_fn = None
     specs = [(synth.noview_state_dict(s, alpha_bias=ab), dict(input_ch_views=0, use_viewdirs=False)) for s, ab in ((20250321, 0.5), (20250322, 0.7))]
