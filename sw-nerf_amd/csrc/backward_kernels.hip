@@ -361,22 +361,39 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
         for (int b = 0; b < 4; ++b) acc[b][r] = 0.f;
     }
     float bs0 = 0.f, bs1 = 0.f, bs3 = 0.f;
+    const bool do_bias = P.bias != nullptr && i0 == 0;       // (w and P.bias are wave-uniform: a scalar branch)
     const int ot2 = 32 * (w & 7), it2 = 32 * (w >> 3);       // B2 rider: this wave's 32 x 32 tile of C2
     issue(0);
     if (HB2 || HA2) { rider_load(0); rider_store(0); }
+    // -DGEMM_EXP_* (tools/experiments/gemm/build.sh; timing experiments, WRONG results, never the shipped library):
+    // NOBARRIER no slab barrier | NODMA only the first two slabs are ever fetched | NOVALU no row masks / bias sums | NOEPI no atomics
 #pragma nounroll
     for (int sl = 0; sl < nslab; ++sl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+#ifndef GEMM_EXP_NOBARRIER
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        const float* Ab = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+#endif
+        float* Abw = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
+        if (valid < GD_SLAB) {
+            // the slice's last, partial slab (once per workgroup): its rows past the slice hold clamped copies of the last row -
+            // zero them on the A side HERE instead of masking every operand of every k-pair (two selects per 4 MFMAs on all 16
+            // waves cost 3-4 % of the whole launch: profiles/r04/gemm_exp.md)
+            for (int e = t; e < (GD_SLAB - valid) * 256; e += 1024) Abw[valid * 256 + e] = 0.f;
+            __syncthreads();
+        }
+        const float* Ab = Abw;
         const float* As = Ab + o0 + i;
         const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
-        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
         // operands of k-pair s+1 are read while the MFMAs of k-pair s run; the first reads go out BEFORE the next
         // slab's DMA is issued, so that its scalar address work hides under their LDS latency
         float a0 = As[hp * 256], a1 = As[hp * 256 + 32], b0 = Bs[hp * 256], b1 = Bs[hp * 256 + 32];
         __builtin_amdgcn_sched_barrier(0);
+#ifdef GEMM_EXP_NODMA
+        if (sl + 1 < 2) {
+#else
         if (sl + 1 < nslab) {
+#endif
             issue(sl + 1);
             if (HB2 || HA2) rider_load(sl + 1);
         }
@@ -384,11 +401,15 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
 #pragma unroll UNR
         for (int s = 0; s < GD_SLAB / 2; ++s) {
             const int row = 2 * s + hp;
-            const bool ok = row < valid;                      // one code path: two selects per 4 MFMAs
+#ifdef GEMM_EXP_OLDMASK                                       // round 3's form, for the A/B in profiles/r04/gemm_exp.md
+            const bool ok = row < valid;
             const float c0 = ok ? a0 : 0.f, c1 = ok ? a1 : 0.f, d0 = b0, d1 = b1;
+#else
+            const float c0 = a0, c1 = a1, d0 = b0, d1 = b1;   // (rows past the slice are zero on the A side: see above)
+#endif
             float e0 = 0.f, e1 = 0.f, f0 = 0.f, f1 = 0.f;
             if (HB2) {                                        // A columns of this wave's C2 tile x B2 columns
-                e0 = Ab[row * 256 + ot2 + i]; e0 = ok ? e0 : 0.f;
+                e0 = Ab[row * 256 + ot2 + i];
                 e1 = b2s[(sl & 1) * GD_B2_FLOATS + row * 64 + it2 + i];
             }
             if (HA2) {                                        // A2 columns (zero padded) x B columns 32(w&7).. (waves 8..15
@@ -400,7 +421,13 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
                 a0 = As[nr]; a1 = As[nr + 32]; b0 = Bs[nr]; b1 = Bs[nr + 32];
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef GEMM_EXP_NOVALU
+#ifdef GEMM_EXP_OLDMASK
             bs0 += c0; bs1 += c1;
+#else
+            if (do_bias) { bs0 += c0; bs1 += c1; }            // wave-uniform: only the four waves of the first column block own bias entries
+#endif
+#endif
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d0, acc[2], 0, 0, 0);
@@ -411,6 +438,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
         }
         if ((HB2 || HA2) && sl + 1 < nslab) rider_store(sl + 1);   // visible after the next barrier
     }
+#ifdef GEMM_EXP_NOEPI
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + accb[0] + acca[0] + bs0 + bs1 + bs3 != 12345.678f) return;
+#endif
     // C/D map: register r of lane (j = i, h = hp) of tile (oa, ib) is row o0 + 32 oa + frow(r,h), column i0 + 32 ib + j
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -421,7 +451,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
             atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
-    if (P.bias && i0 == 0) {
+    if (do_bias) {
         bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
         if (hp == 0) { atomicAdd(P.bias + o0 + i, bs0); atomicAdd(P.bias + o0 + 32 + i, bs1); }
     }
@@ -519,10 +549,18 @@ __global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
         if (sl + 1 < nslab) issue(sl + 1);
         if (!active) continue;
-        const float* Ab = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+        float* Abw = gd_lds + (sl & 1) * GD_BUF_FLOATS;
+        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
+        if (valid < GD_SLAB) {
+            // the slice's last, partial slab (once per workgroup): its rows past the slice hold clamped copies of the last row -
+            // zero them on the A side HERE instead of masking every operand of every k-pair (two selects per 4 MFMAs on all 16
+            // waves cost 3-4 % of the whole launch: profiles/r04/gemm_exp.md)
+            for (int e = t; e < (GD_SLAB - valid) * 256; e += 1024) Abw[valid * 256 + e] = 0.f;
+            __syncthreads();
+        }
+        const float* Ab = Abw;
         const float* As = Ab + o0 + i;
         const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
-        const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
         float a[TO], b[TI];
 #pragma unroll
         for (int x = 0; x < TO; ++x) a[x] = As[hp * 256 + 32 * x];
