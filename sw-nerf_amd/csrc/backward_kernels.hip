@@ -830,6 +830,44 @@ struct Narrow5 {
     float* c0s; float* cvs; float* G; float* a4w; float* rgb4; float* b_l0; float* b_hv; float* a4b; float* rgb4b;
 };
 
+// One 16-row slab of one wave's four tiles, with COMPILE-TIME operand pitches: every LDS read is base + immediate offset, the
+// k-pairs are fully unrolled, and nothing but the MFMAs (and, on the waves that own bias entries, two adds) sits between the
+// reads - round 3's loop carried 4 selects, 4 adds and 8 pointer increments per 4 MFMAs, and VALU instructions between MFMAs
+// cost far more than their issue slots (profiles/r04/gemm_exp.md).  NA / NB: distinct A / B column blocks among the four tiles
+// (2 x 2 block: tile k = A block k>>1 x B block k&1; 4 x 1: A block k; 1 x 4: B block k) - 4 or 5 LDS reads per k-pair, not 8.
+// Rows past the slice are zero on the A side (the caller zeroes them once); lanes past a 4-column A operand compute rows of the
+// tile that are never written.
+template <int AP, int BP, int NA, int NB>
+__device__ __forceinline__ void n5_slab(const float* lds, int ia, int ib, const int (&acol)[4], const int (&bcol)[4], f32x16 (&acc)[4],
+                                        float& bs0, float& bs2, bool do_bias) {
+    int pa[NA], pb[NB];
+    float a[NA], b[NB];
+#pragma unroll
+    for (int x = 0; x < NA; ++x) { pa[x] = ia + acol[NA == 2 ? 2 * x : x]; a[x] = lds[pa[x]]; }
+#pragma unroll
+    for (int y = 0; y < NB; ++y) { pb[y] = ib + bcol[y]; b[y] = lds[pb[y]]; }
+#pragma unroll
+    for (int s = 0; s < N5_SLAB / 2; ++s) {
+        float c[NA], d[NB];
+#pragma unroll
+        for (int x = 0; x < NA; ++x) c[x] = a[x];
+#pragma unroll
+        for (int y = 0; y < NB; ++y) d[y] = b[y];
+        if (s + 1 < N5_SLAB / 2) {
+#pragma unroll
+            for (int x = 0; x < NA; ++x) a[x] = lds[pa[x] + 2 * (s + 1) * AP];
+#pragma unroll
+            for (int y = 0; y < NB; ++y) b[y] = lds[pb[y] + 2 * (s + 1) * BP];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias) { bs0 += c[0]; bs2 += c[NA == 2 ? 1 : 0]; }     // column sums of the A blocks of tiles 0 and 2 (wave-uniform branch)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[NA == 4 ? k : (NA == 2 ? k >> 1 : 0)], d[NB == 4 ? k : (NB == 2 ? k & 1 : 0)], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
     extern __shared__ __attribute__((aligned(16))) float n5_lds[];          // [2][N5_BUF]
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, hp = lane >> 5;
@@ -886,69 +924,65 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
             ws_dma(reinterpret_cast<const char*>(P.d_out + (m0 + ra) * 4), (unsigned)((rowc(min(lane, N5_SLAB - 1)) - ra) * 16), buf + (unsigned)(N5_A2 * 4));
         }
     };
-    // ONE code path for all waves (role branches around the MFMAs made hipcc copy and spill the accumulators): tile k of wave w
-    // multiplies columns acol[k].. of its A operand (LDS offset asrc, row pitch ap, alim valid columns per 32: 4 for d raw) by
-    // columns bcol[k].. of its B operand - all wave-uniform scalars
-    int asrc, ap, alim = 32, bsrc, bp, acol[4], bcol[4];
+    // tile k of wave w multiplies columns acol[k].. of its A operand (LDS offset asrc) by columns bcol[k].. of its B operand - wave-uniform
+    // scalars; the operand PITCHES are compile-time per role (n5_slab): the slab loop below dispatches on the role once per slab
+    int asrc, bsrc, acol[4], bcol[4];
     if (w < 8) {                                             // G: A = d pre_hv tiles 2p, 2p+1; B = h7 tiles 2q, 2q+1
-        asrc = N5_A1; ap = 128; bsrc = N5_B1; bp = 256;
+        asrc = N5_A1; bsrc = N5_B1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acol[k] = 64 * (w & 1) + 32 * (k >> 1); bcol[k] = 64 * (w >> 1) + 32 * (k & 1); }
     } else if (w < 12) {                                     // pts_linears.0: A = d pre_0 tiles 2(w-8), +1; B = xs tiles 0, 1
-        asrc = N5_A0; ap = 256; bsrc = N5_B0; bp = SW_XS_LD;
+        asrc = N5_A0; bsrc = N5_B0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acol[k] = 64 * (w - 8) + 32 * (k >> 1); bcol[k] = 32 * (k & 1); }
     } else if (w == 12) {                                    // gamma(d) columns: A = d pre_hv tiles 0..3; B = xs tile 2
-        asrc = N5_A1; ap = 128; bsrc = N5_B0; bp = SW_XS_LD;
+        asrc = N5_A1; bsrc = N5_B0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acol[k] = 32 * k; bcol[k] = 64; }
     } else {                                                 // d raw (4 columns) x h7 tiles 4(w-13).. (w = 13, 14) or hv tiles 0..3 (w = 15)
-        asrc = N5_A2; ap = 4; alim = 4; bsrc = w < 15 ? N5_B1 : N5_B2; bp = w < 15 ? 256 : 128;
+        asrc = N5_A2; bsrc = w < 15 ? N5_B1 : N5_B2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { acol[k] = 0; bcol[k] = (w < 15 ? 128 * (w - 13) : 0) + 32 * k; }
     }
-    const bool acolumn = i < alim;
+    // which waves own bias entries (column sums of their A blocks): d pre_hv -> waves 0, 1; d pre_0 -> 8..11; d raw -> 13 and 15
+    const bool do_bias = (w < 2 && P.b_hv) || (w >= 8 && w < 12 && P.b_l0) || (w == 13 && P.a4b) || (w == 15 && P.rgb4b);
     f32x16 acc[4];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float bs0 = 0.f, bs2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    issue(0);
+    // The WHOLE slab loop once per role (the role test in front of it, not inside): with the dispatch inside the loop hipcc keeps
+    // the 64 accumulator registers alive across five code paths and spills 388 B per lane at this kernel's 128-register budget.
+    // Every copy executes the same barriers, so the waves of a workgroup stay in step whichever copy they run.
+    auto run = [&](auto ap_, auto bp_, auto na_, auto nb_, bool bias) {
+        constexpr int AP = decltype(ap_)::value, BP = decltype(bp_)::value, NA = decltype(na_)::value, NB = decltype(nb_)::value;
+        issue(0);
 #pragma nounroll
-    for (int sl = 0; sl < nslab; ++sl) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
-        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        if (sl + 1 < nslab) issue(sl + 1);
-        const int valid = mlen - sl * N5_SLAB;
-        // operands of k-pair s+1 are read while the MFMAs of k-pair s run; one pointer per operand stream, advanced by two rows
-        // per k-pair (the last prefetch reads two rows past the slab: the next operand's region of the same buffer - unused)
-        int pa[4], pb[4];                                    // 32-bit LDS indices (generic pointers cost two registers each)
-        float a[4], b[4];
-        const int ia = (sl & 1) * N5_BUF + asrc + (acolumn ? i : 0) + hp * ap, ib = (sl & 1) * N5_BUF + bsrc + i + hp * bp;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pa[k] = ia + acol[k]; pb[k] = ib + bcol[k]; a[k] = n5_lds[pa[k]]; b[k] = n5_lds[pb[k]]; }
-#pragma unroll 2
-        for (int s = 0; s < N5_SLAB / 2; ++s) {
-            const bool ok = acolumn && (2 * s + hp) < valid;
-            float c[4], d[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; pa[k] += 2 * ap; pb[k] += 2 * bp; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = n5_lds[pa[k]]; b[k] = n5_lds[pb[k]]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                bs[k] += c[k];
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[k], d[k], acc[k], 0, 0, 0);
+        for (int sl = 0; sl < nslab; ++sl) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+            __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+            const int valid = mlen - sl * N5_SLAB;
+            const int buf = (sl & 1) * N5_BUF;
+            if (valid < N5_SLAB) {
+                // the slice's last, partial slab: its rows past the slice hold clamped copies - zero them on the A side (d pre_0,
+                // d pre_hv, d raw) once, instead of masking every operand of every k-pair
+                for (int e = t; e < (N5_SLAB - valid) * 256; e += 1024) n5_lds[buf + N5_A0 + valid * 256 + e] = 0.f;
+                for (int e = t; e < (N5_SLAB - valid) * 128; e += 1024) n5_lds[buf + N5_A1 + valid * 128 + e] = 0.f;
+                if (t < (N5_SLAB - valid) * 4) n5_lds[buf + N5_A2 + valid * 4 + t] = 0.f;
+                __syncthreads();
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (sl + 1 < nslab) issue(sl + 1);
+            n5_slab<AP, BP, NA, NB>(n5_lds, buf + asrc + i + hp * AP, buf + bsrc + i + hp * BP, acol, bcol, acc, bs0, bs2, bias);
         }
-    }
-    // C/D map: register r of lane (j = i, h = hp) of tile k is row acol[k] + frow(r,h) of the A operand's columns, column bcol[k] + j
-    // of the B operand's (relative to the product's block)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32, 64);          // rows 2s and 2s+1 sit in the two lane halves
+    };
+    using std::integral_constant;
+    if (w < 8) run(integral_constant<int, 128>{}, integral_constant<int, 256>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}, do_bias);
+    else if (w < 12) run(integral_constant<int, 256>{}, integral_constant<int, SW_XS_LD>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}, do_bias);
+    else if (w == 12) run(integral_constant<int, 128>{}, integral_constant<int, SW_XS_LD>{}, integral_constant<int, 4>{}, integral_constant<int, 1>{}, false);
+    else if (w < 15) run(integral_constant<int, 4>{}, integral_constant<int, 256>{}, integral_constant<int, 1>{}, integral_constant<int, 4>{}, do_bias);
+    else run(integral_constant<int, 4>{}, integral_constant<int, 128>{}, integral_constant<int, 1>{}, integral_constant<int, 4>{}, do_bias);
+    bs0 += __shfl_xor(bs0, 32, 64); bs2 += __shfl_xor(bs2, 32, 64);        // rows 2s and 2s+1 sit in the two lane halves
     float* C; int ldc, rlim = 256, cshift = 0;
     if (w < 8) { C = P.G; ldc = 256; }
     else if (w < 12) { C = P.c0s; ldc = 64; }
@@ -964,10 +998,10 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
         }
     // column sums of the A operands: one wave per A tile writes them (tiles k = 0 and k = 2 of a 2 x 2 block hold different A tiles)
     if (hp == 0) {
-        if (w < 2 && P.b_hv) { atomicAdd(P.b_hv + acol[0] + i, bs[0]); atomicAdd(P.b_hv + acol[2] + i, bs[2]); }
-        if (w >= 8 && w < 12 && P.b_l0) { atomicAdd(P.b_l0 + acol[0] + i, bs[0]); atomicAdd(P.b_l0 + acol[2] + i, bs[2]); }
-        if (w == 13 && P.a4b && i < 4) atomicAdd(P.a4b + i, bs[0]);
-        if (w == 15 && P.rgb4b && i < 4) atomicAdd(P.rgb4b + i, bs[0]);
+        if (w < 2 && P.b_hv) { atomicAdd(P.b_hv + acol[0] + i, bs0); atomicAdd(P.b_hv + acol[2] + i, bs2); }
+        if (w >= 8 && w < 12 && P.b_l0) { atomicAdd(P.b_l0 + acol[0] + i, bs0); atomicAdd(P.b_l0 + acol[2] + i, bs2); }
+        if (w == 13 && P.a4b && i < 4) atomicAdd(P.a4b + i, bs0);
+        if (w == 15 && P.rgb4b && i < 4) atomicAdd(P.rgb4b + i, bs0);
     }
 }
 
@@ -1009,14 +1043,14 @@ extern "C" int swnerf_canon_narrow_grads(const float* grad, int ldg, const float
 struct NpOp { const float* ptr; int ld; int width; int lds_off; int kib; };      // width: floats staged per row (multiple of 4); kib: 1-KiB pieces per slab image
 struct NpWave {
     short a_op, b_op;              // operand indices; a_op < 0: this wave only helps with the DMA
-    short alim;                    // valid A columns of a 32-column block (4 / 8 for d dx / d raw, else 32)
+    short shape;                   // which compile-time tile shape its four tiles have (narrow_plan_kernel: 1..4)
     short rlim, cshift, bias_lim;  // output rows < rlim; C column = B column - cshift; bias entries < bias_lim per block
     short acol[4], bcol[4];
     float* C; int ldc; int bias_mask;   // bit k: the column sums of this wave's A block k go to bias[acol[k] + i]
     float* bias;
     unsigned char job_op[NP_MAX_JOBS]; unsigned char job_kib[NP_MAX_JOBS];      // DMA duty: piece job_kib of operand job_op (255: none)
 };
-struct NpPlan { int64_t M, rows_per_wg; int buf_floats; NpOp op[NP_MAX_OPS]; NpWave wave[16]; };
+struct NpPlan { int64_t M, rows_per_wg; int buf_floats; int a_ops; NpOp op[NP_MAX_OPS]; NpWave wave[16]; };   // a_ops: bit o = operand o is an A side
 
 __global__ void __launch_bounds__(1024) narrow_plan_kernel(NpPlan P) {
     extern __shared__ __attribute__((aligned(16))) float np_lds[];          // [2][buf_floats]
@@ -1062,51 +1096,50 @@ __global__ void __launch_bounds__(1024) narrow_plan_kernel(NpPlan P) {
     const bool active = R.a_op >= 0;
     const NpOp& OA = P.op[active ? R.a_op : 0];
     const NpOp& OB = P.op[active ? R.b_op : 0];
-    const int asrc = OA.lds_off, ap = OA.width, bsrc = OB.lds_off, bp = OB.width, alim = R.alim;
+    const int asrc = OA.lds_off, bsrc = OB.lds_off;
     int acol[4], bcol[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { acol[k] = R.acol[k]; bcol[k] = R.bcol[k]; }
-    const bool acolumn = i < alim;
     f32x16 acc[4];
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-    issue(0);
+    const bool do_bias = R.bias != nullptr;
+    // the whole slab loop once per tile shape (operand pitches and block pattern are compile-time inside: n5_slab), the shape test
+    // in front of the loop - see narrow5_kernel.  shape 0: idle (DMA only)
+    auto run = [&](auto ap_, auto bp_, auto na_, auto nb_) {
+        constexpr int AP = decltype(ap_)::value, BP = decltype(bp_)::value, NA = decltype(na_)::value, NB = decltype(nb_)::value;
+        issue(0);
 #pragma nounroll
-    for (int sl = 0; sl < nslab; ++sl) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
-        __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        if (sl + 1 < nslab) issue(sl + 1);
-        if (!active) continue;
-        const int valid = mlen - sl * NP_SLAB;
-        int pa[4], pb[4];
-        float a[4], b[4];
-        const int ia = (sl & 1) * P.buf_floats + asrc + (acolumn ? i : 0) + hp * ap, ib = (sl & 1) * P.buf_floats + bsrc + i + hp * bp;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pa[k] = ia + acol[k]; pb[k] = ib + bcol[k]; a[k] = np_lds[pa[k]]; b[k] = np_lds[pb[k]]; }
-#pragma unroll 2
-        for (int s = 0; s < NP_SLAB / 2; ++s) {
-            const bool ok = acolumn && (2 * s + hp) < valid;
-            float c[4], d[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { c[k] = ok ? a[k] : 0.f; d[k] = b[k]; pa[k] += 2 * ap; pb[k] += 2 * bp; }
-            // (the last prefetch reads two rows past the slab image: the next operand's region or the pad behind the buffer)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] = np_lds[pa[k]]; b[k] = np_lds[pb[k]]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                bs[k] += c[k];
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[k], d[k], acc[k], 0, 0, 0);
+        for (int sl = 0; sl < nslab; ++sl) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+            __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+            const int valid = mlen - sl * NP_SLAB;
+            const int buf = (sl & 1) * P.buf_floats;
+            if (valid < NP_SLAB) {                                // the slice's last, partial slab: zero the rows past it on the A side(s)
+                for (int o = 0; o < NP_MAX_OPS; ++o) {
+                    if (!((P.a_ops >> o) & 1)) continue;
+                    const int wd = P.op[o].width;
+                    for (int e = t; e < (NP_SLAB - valid) * wd; e += 1024) np_lds[buf + P.op[o].lds_off + valid * wd + e] = 0.f;
+                }
+                __syncthreads();
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (sl + 1 < nslab) issue(sl + 1);
+            if constexpr (NA > 0) n5_slab<AP, BP, NA, NB>(np_lds, buf + asrc + i + hp * AP, buf + bsrc + i + hp * BP, acol, bcol, acc, bs[0], bs[2], do_bias);
         }
+    };
+    using std::integral_constant;
+    switch (active ? R.shape : 0) {
+        case 1: run(integral_constant<int, 256>{}, integral_constant<int, SW_XS_LD>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+        case 2: run(integral_constant<int, 256>{}, integral_constant<int, SW_XS_LD>{}, integral_constant<int, 4>{}, integral_constant<int, 1>{}); break;
+        case 3: run(integral_constant<int, 4>{}, integral_constant<int, 256>{}, integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+        case 4: run(integral_constant<int, 8>{}, integral_constant<int, 256>{}, integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+        default: run(integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
     }
     if (!active) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32, 64);          // rows 2s and 2s+1 sit in the two lane halves
+    bs[0] += __shfl_xor(bs[0], 32, 64); bs[2] += __shfl_xor(bs[2], 32, 64);  // rows 2s and 2s+1 sit in the two lane halves
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1125,10 +1158,10 @@ __global__ void __launch_bounds__(1024) narrow_plan_kernel(NpPlan P) {
 struct NpBuilder {
     NpPlan P; int n_ops, cursor;
     NpBuilder(int64_t M) : n_ops(0), cursor(0) {
-        P.M = M;
+        P.M = M; P.a_ops = 0;
         for (int w = 0; w < 16; ++w) {
             NpWave& R = P.wave[w];
-            R.a_op = -1; R.b_op = 0; R.alim = 32; R.rlim = 0; R.cshift = 0; R.bias_lim = 32; R.C = nullptr; R.ldc = 0; R.bias_mask = 0; R.bias = nullptr;
+            R.a_op = -1; R.b_op = 0; R.shape = 0; R.rlim = 0; R.cshift = 0; R.bias_lim = 32; R.C = nullptr; R.ldc = 0; R.bias_mask = 0; R.bias = nullptr;
             for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = 0; }
             for (int j = 0; j < NP_MAX_JOBS; ++j) { R.job_op[j] = 255; R.job_kib[j] = 0; }
         }
@@ -1141,9 +1174,11 @@ struct NpBuilder {
         cursor += O.kib * 256;                               // whole KiB pieces: a DMA instruction always writes 1 KiB
         return n_ops++;
     }
-    NpWave& wave(int w, int a_op, int b_op, float* C, int ldc, int rlim) {
+    // shape: 1 = 256-wide A x xs, 2 x 2 block | 2 = 256-wide A x xs, 4 x 1 | 3 = 4-column A x 256-wide B, 1 x 4 | 4 = 8-column A x 256-wide B, 1 x 4
+    NpWave& wave(int w, int shape, int a_op, int b_op, float* C, int ldc, int rlim) {
         NpWave& R = P.wave[w];
-        R.a_op = (short)a_op; R.b_op = (short)b_op; R.C = C; R.ldc = ldc; R.rlim = (short)rlim;
+        R.shape = (short)shape; R.a_op = (short)a_op; R.b_op = (short)b_op; R.C = C; R.ldc = ldc; R.rlim = (short)rlim;
+        P.a_ops |= 1 << a_op;
         return R;
     }
     int launch(const char* what, void* stream) {
@@ -1185,18 +1220,17 @@ extern "C" int swnerf_deform_narrow_grads(const float* grad_d, int ldg, const fl
     NpBuilder B(M);
     const int o_g = B.op(grad_d, ldg, 256), o_x = B.op(xs_d, SW_XS_LD, SW_XS_LD), o_h = B.op(act_d + 1792, lda, 256), o_d = B.op(g_dx, 4, 4);
     for (int w = 0; w < 4; ++w) {                                                // gamma(x) slots: A tiles 2w, 2w+1 x xs tiles 0, 1
-        NpWave& R = B.wave(w, o_g, o_x, c0s, 64, 256);
+        NpWave& R = B.wave(w, 1, o_g, o_x, c0s, 64, 256);
         for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(64 * w + 32 * (k >> 1)); R.bcol[k] = (short)(32 * (k & 1)); }
         R.bias = b_l0; R.bias_mask = 0x5;
     }
     for (int w = 4; w < 6; ++w) {                                                // gamma(t) slots: A tiles 4(w-4)..+3 x xs tile 2
-        NpWave& R = B.wave(w, o_g, o_x, cts, 32, 256);
+        NpWave& R = B.wave(w, 2, o_g, o_x, cts, 32, 256);
         for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(128 * (w - 4) + 32 * k); R.bcol[k] = 64; }
         R.cshift = 64;
     }
     for (int w = 6; w < 8; ++w) {                                                // _time_out: d dx (4 columns) x h7 tiles 4(w-6)..+3
-        NpWave& R = B.wave(w, o_d, o_h, w4, 256, 4);
-        R.alim = 4;
+        NpWave& R = B.wave(w, 3, o_d, o_h, w4, 256, 4);
         for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = (short)(128 * (w - 6) + 32 * k); }
         if (w == 6) { R.bias = b4; R.bias_mask = 0x1; R.bias_lim = 4; }
     }
@@ -1217,13 +1251,12 @@ extern "C" int swnerf_noview_narrow_grads(const float* grad, int ldg, const floa
     NpBuilder B(M);
     const int o_g = B.op(grad, ldg, 256), o_x = B.op(xs, SW_XS_LD, SW_XS_LD), o_h = B.op(act + 1792, lda, 256), o_d = B.op(d_raw8, 8, 8);
     for (int w = 0; w < 4; ++w) {
-        NpWave& R = B.wave(w, o_g, o_x, c0s, 64, 256);
+        NpWave& R = B.wave(w, 1, o_g, o_x, c0s, 64, 256);
         for (int k = 0; k < 4; ++k) { R.acol[k] = (short)(64 * w + 32 * (k >> 1)); R.bcol[k] = (short)(32 * (k & 1)); }
         R.bias = b_l0; R.bias_mask = 0x5;
     }
     for (int w = 4; w < 6; ++w) {                                                // output_linear: d raw (8 columns) x h7 tiles 4(w-4)..+3
-        NpWave& R = B.wave(w, o_d, o_h, w8, 256, 8);
-        R.alim = 8;
+        NpWave& R = B.wave(w, 4, o_d, o_h, w8, 256, 8);
         for (int k = 0; k < 4; ++k) { R.acol[k] = 0; R.bcol[k] = (short)(128 * (w - 4) + 32 * k); }
         if (w == 4) { R.bias = b8; R.bias_mask = 0x1; R.bias_lim = 8; }
     }
