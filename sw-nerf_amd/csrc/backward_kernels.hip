@@ -268,6 +268,9 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
 // slab.  Wave w owns the 64 x 64 block o in [64(w&3), +64), i in [64(w>>2), +64) as 2 x 2 accumulator tiles:
 // 4 LDS reads per 4 MFMAs.
 #define GD_SLAB 32
+#ifndef GD_RIDER_UNR
+#define GD_RIDER_UNR 8
+#endif
 #define GD_BUF_FLOATS (2 * GD_SLAB * 256)            // A slab then B slab
 #define GD_B2_FLOATS (GD_SLAB * 64)                  // optional second B operand, <= 64 columns
 #define GD_A2_FLOATS (GD_SLAB * 32)                  // optional second A operand, <= 32 columns (zero padded)
@@ -397,7 +400,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
             issue(sl + 1);
             if (HB2 || HA2) rider_load(sl + 1);
         }
-        constexpr int UNR = (HB2 || HA2) ? 4 : GD_SLAB / 2;    // a rider's extra tile leaves no registers for a full unroll
+        constexpr int UNR = (HB2 || HA2) ? GD_RIDER_UNR : GD_SLAB / 2;    // a rider's extra tile leaves fewer registers for the unroll
 #pragma unroll UNR
         for (int s = 0; s < GD_SLAB / 2; ++s) {
             const int row = 2 * s + hp;
@@ -542,22 +545,22 @@ __global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 #pragma unroll
     for (int a = 0; a < TO; ++a) bs[a] = 0.f;
+    const bool do_bias = P.bias != nullptr && i0 == 0;       // (wave-uniform)
     issue(0);
 #pragma nounroll
     for (int sl = 0; sl < nslab; ++sl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
         __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
-        if (sl + 1 < nslab) issue(sl + 1);
-        if (!active) continue;
         float* Abw = gd_lds + (sl & 1) * GD_BUF_FLOATS;
         const int valid = mlen - sl * GD_SLAB;                // rows of this slab inside the slice (>= 32: all)
         if (valid < GD_SLAB) {
-            // the slice's last, partial slab (once per workgroup): its rows past the slice hold clamped copies of the last row -
-            // zero them on the A side HERE instead of masking every operand of every k-pair (two selects per 4 MFMAs on all 16
-            // waves cost 3-4 % of the whole launch: profiles/r04/gemm_exp.md)
+            // the slice's last, partial slab (once per workgroup, ALL waves: also the ones that only help with the DMA): its rows past
+            // the slice hold clamped copies of the last row - zero them on the A side instead of masking every operand of every k-pair
             for (int e = t; e < (GD_SLAB - valid) * 256; e += 1024) Abw[valid * 256 + e] = 0.f;
             __syncthreads();
         }
+        if (sl + 1 < nslab) issue(sl + 1);
+        if (!active) continue;
         const float* Ab = Abw;
         const float* As = Ab + o0 + i;
         const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
@@ -569,10 +572,9 @@ __global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
 #pragma unroll
         for (int s = 0; s < GD_SLAB / 2; ++s) {
             const int row = 2 * s + hp;
-            const bool ok = row < valid;
             float c[TO], d[TI];
 #pragma unroll
-            for (int x = 0; x < TO; ++x) c[x] = ok ? a[x] : 0.f;
+            for (int x = 0; x < TO; ++x) c[x] = a[x];         // (rows past the slice are zero on the A side: see above)
 #pragma unroll
             for (int x = 0; x < TI; ++x) d[x] = b[x];
             const int nr = (min(row + 2, GD_SLAB - 1)) * 256;   // (the last iteration re-reads the slab's last rows: unused)
@@ -581,8 +583,10 @@ __global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
 #pragma unroll
             for (int x = 0; x < TI; ++x) b[x] = Bs[nr + 32 * x];
             __builtin_amdgcn_sched_barrier(0);
+            if (do_bias) {                                    // only the waves of the first column block own bias entries
 #pragma unroll
-            for (int x = 0; x < TO; ++x) bs[x] += c[x];
+                for (int x = 0; x < TO; ++x) bs[x] += c[x];
+            }
 #pragma unroll
             for (int x = 0; x < TO; ++x)
 #pragma unroll
@@ -603,7 +607,7 @@ __global__ void __launch_bounds__(1024) gemm_tn_tiled_kernel(GemmTN P) {
                 if (o < P.No && col < P.Ni) atomicAdd(P.C + (size_t)o * P.ldc + col, acc[x * TI + y][r]);
             }
         }
-    if (P.bias && i0 == 0) {
+    if (do_bias) {
 #pragma unroll
         for (int x = 0; x < TO; ++x) {
             const float v = bs[x] + __shfl_xor(bs[x], 32, 64);
