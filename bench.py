@@ -188,9 +188,11 @@ def build_scene(cfg, dev, rank):
     if cfg == "C5":
         embedtime_fn, input_ch_time = embedder.get_embedder(10, 1, 0)
         sd = synth.dnerf_state_dict(synth.NET_DNERF[0], alpha_bias=synth.NET_DNERF[1])
-        net = model.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4],
-                                     input_ch_views=input_ch_views, input_ch_time=input_ch_time, use_viewdirs=True,
-                                     embed_fn=embed_fn, zero_canonical=True)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):     # the factory prints "NeRF type selected: ..." like the reference's (model.py:216): stdout is ONE JSON line
+            net = model.NeRF.get_by_name("direct_temporal", D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4],
+                                         input_ch_views=input_ch_views, input_ch_time=input_ch_time, use_viewdirs=True,
+                                         embed_fn=embed_fn, zero_canonical=True)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         net = net.to(dev).eval()
         sc["sds_np"] = [sd]
