@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
 // 4 LDS reads per 4 MFMAs.
 #define GD_SLAB 32
 #ifndef GD_RIDER_UNR
-#define GD_RIDER_UNR 8
+#define GD_RIDER_UNR 4                    // (8 measures the same, 16 spills: profiles/r04/gemm_exp.md)
 #endif
 #define GD_BUF_FLOATS (2 * GD_SLAB * 256)            // A slab then B slab
 #define GD_B2_FLOATS (GD_SLAB * 64)                  // optional second B operand, <= 64 columns
