@@ -271,10 +271,11 @@ __device__ __forceinline__ void x3_canon(float px, float py, float pz, int h, co
         X3_PROBE(1, q3);
     }
     const float* hb = nullptr;
-    // pts_linears[1..7] and feature_linear (l == 8, no activation) share ONE body: the accumulators then have one home in
-    // the register file (three differently shaped bodies in one loop made the compiler shuffle 48 of them through scratch)
+    // pts_linears[1..7] share ONE body: the accumulators then have one home in the register file (three differently shaped bodies
+    // in one loop made the compiler shuffle 48 of them through scratch).  feature_linear is folded into the view layer (round 4,
+    // swnerf_common.h SW_CANON_STEPS): the view layer below runs on the split of relu(h_7) with the folded weights.
 #pragma nounroll
-    for (int l = 1; l <= 8; ++l) {
+    for (int l = 1; l <= 7; ++l) {
         SW_STAMP(q0);
         x3_seg<8, 0, 16, SEG_BIAS, TERMS>(acc, bhi, blo, xs);
         X3_PROBE(0, q0);
@@ -308,17 +309,16 @@ __device__ __forceinline__ void x3_canon(float px, float py, float pz, int h, co
             hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;                 // [b_alpha, b_r, b_g, b_b]
             xs.bias += 9 * SW_BIAS_TILE_FLOATS;
         }
-        const float floor = (l == 8) ? -__builtin_inff() : 0.f;     // feature_linear has no activation
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], floor);
+            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], 0.f);
             __builtin_amdgcn_sched_barrier(0);
         }
         X3_PROBE(1, q3);
     }
     f32x16 hv[4];
     SW_STAMP(q6);
-    x3_seg<4, 0, 16, SEG_BIAS, TERMS>(hv, bhi, blo, xs);           // views_linears[0] on cat[feature, input_views]: feature ...
+    x3_seg<4, 0, 16, SEG_BIAS, TERMS>(hv, bhi, blo, xs);           // views_linears[0] . feature_linear (folded) on relu(h_7) ...
     X3_PROBE(0, q6);
     {
         f32x16 demb;
@@ -376,9 +376,8 @@ __device__ __forceinline__ void x3_net_dn(float px, float py, float pz, float ft
         }
     }
     const float* hb = nullptr;
-    const int last = deform ? 7 : 8;                                // the canonical net's feature_linear rides as layer 8
 #pragma nounroll
-    for (int l = 1; l <= last; ++l) {
+    for (int l = 1; l <= 7; ++l) {                                  // (feature_linear is folded into the canonical net's view layer)
         x3_seg<8, 0, 16, SEG_BIAS, TERMS>(acc, bhi, blo, xs);
         if (l == 5) {
             f32x16 emb[2];
@@ -410,10 +409,9 @@ __device__ __forceinline__ void x3_net_dn(float px, float py, float pz, float ft
             hb = xs.bias + nout * 8 * SW_BIAS_TILE_FLOATS;           // canonical: [b_alpha, b_r, b_g, b_b]
             xs.bias += (nout * 8 + 1) * SW_BIAS_TILE_FLOATS;
         }
-        const float floor = (l == 8) ? -__builtin_inff() : 0.f;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], floor);
+            x3_split<true>(acc[n], bhi[2 * n], blo[2 * n], bhi[2 * n + 1], blo[2 * n + 1], 0.f);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -550,9 +548,10 @@ __device__ __forceinline__ void x3_canon_pipe(float px, float py, float pz, int 
     }
     float hs = 0.f;
     const float* hb = nullptr;
-    // layer pairs (1,2) (3,4) (5,6) (7, feature_linear): odd layers A -> B, even layers B -> A
+    // layer pairs (1,2) (3,4) (5,6): odd layers A -> B, even layers B -> A; then layer 7 (A -> B) and the view layer on relu(h_7)
+    // with feature_linear folded into its weights (round 4) - alpha_linear rides on that layer's split of h_7
 #pragma nounroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {
         x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);
         if (i == 2) {                                               // layer 5: ... then gamma(x) (model.py:45-46)
             f32x16 emb[2];
@@ -563,16 +562,15 @@ __device__ __forceinline__ void x3_canon_pipe(float px, float py, float pz, int 
             x3_split<false>(emb[1], ehi[2], elo[2], ehi[3], elo[3]);
             x3_seg<8, 0, 4, SEG_ACC, TERMS>(B, ehi, elo, xs);
         }
-        // i == 3: this is feature_linear on relu(h_7), and alpha_linear rides on the split of h_7 (8 weight tiles + the
-        // head-bias tile sit in front of feature_linear's bias tiles)
-        const float* hw = (i == 3) ? xs.bias : nullptr;
-        if (i == 3) hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;
-        x3_player<8, TERMS>(A, B, 0.f, hw, hs, i == 3 ? 9 : 0, xs);
+        x3_player<8, TERMS>(A, B, 0.f, nullptr, dummy, 0, xs);
     }
+    x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);             // layer 7
+    const float* hw = xs.bias;                                      // alpha_linear: 8 weight tiles + the head-bias tile, in front of b_vf
+    hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;
+    f32x16 hv[4];
+    x3_player<4, TERMS>(hv, B, 0.f, hw, hs, 9, xs);                    // views_linears[0] . feature_linear (folded) on relu(h_7) ...
     hs += __shfl_xor(hs, 32, 64);
     sigma = hs + hb[0];
-    f32x16 hv[4];
-    x3_player<4, TERMS>(hv, A, -__builtin_inff(), nullptr, dummy, 0, xs);    // views_linears[0]: the feature (no activation) ...
     {
         f32x16 demb;
         tile_fetch(lds_dir, lane, demb);
@@ -618,7 +616,7 @@ __device__ __forceinline__ void x3_net_dn_pipe(float px, float py, float pz, flo
             x3_seg<8, 0, 4, SEG_BIAS, TERMS>(A, ehi, elo, xs);
         }
     }
-    // layer pairs (1,2) (3,4) (5,6) in one loop body, then layer 7; only the canonical net goes on (feature_linear, views)
+    // layer pairs (1,2) (3,4) (5,6) in one loop body, then layer 7; only the canonical net goes on (the view layer)
 #pragma nounroll
     for (int i = 0; i < 3; ++i) {
         x3_player<8, TERMS>(B, A, 0.f, nullptr, dummy, 0, xs);
@@ -656,11 +654,10 @@ __device__ __forceinline__ void x3_net_dn_pipe(float px, float py, float pz, flo
     float hs = 0.f;
     const float* hw = xs.bias;                                      // alpha_linear rides on the split of h_7 (x3_canon_pipe)
     const float* hb = xs.bias + 8 * SW_BIAS_TILE_FLOATS;
-    x3_player<8, TERMS>(A, B, 0.f, hw, hs, 9, xs);                     // feature_linear
+    f32x16 hv[4];
+    x3_player<4, TERMS>(hv, B, 0.f, hw, hs, 9, xs);                    // the view layer with feature_linear folded in, on relu(h_7)
     hs += __shfl_xor(hs, 32, 64);
     head[0] = hs + hb[0];
-    f32x16 hv[4];
-    x3_player<4, TERMS>(hv, A, -__builtin_inff(), nullptr, dummy, 0, xs);
     {
         f32x16 demb;
         pe_dir(v0, v1, v2, h, demb);

@@ -283,15 +283,15 @@ extern "C" int swnerf_pack_net(int kind, const float* const* params, int L_pos, 
     return vl.flush();
 }
 
-// The canonical net's bias / head tiles in the UNFOLDED order (SW_X3_CANON_BIAS_TILES): what the bf16x3 core consumes, which
-// still runs feature_linear as its own layer (mlp_core_x3.h).  Called by swnerf_pack_net_x3_kind (x3_kernels.hip).
-int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStream_t st) {
+// The canonical net's bias / head tiles in the order the bf16x3 core consumes them (SW_X3_CANON_BIAS_TILES): the fp32 stream's
+// tiles with b_vf behind the head-bias tile instead of in front (that core has no per-ray DIR prefix).  `fold`: the folded matrix of
+// the fp32 blob made from the same tensors (b_vf sits behind its 128 rows).  Called by swnerf_pack_net_x3_kind (x3_kernels.hip).
+int sw_pack_canon_bias_x3(const float* const* params, const float* fold, float* dst, hipStream_t st) {
     Packer pk(st, nullptr, dst, 0, 0, 0);
     for (int l = 0; l < 8; ++l) pk.btiles(params[2 * l + 1], 256, 8);                  // pts_linears.l.bias
     pk.vecs(params[20], 1, 256);                                                       // alpha_linear.weight
     pk.headbias(params[21], 1, params[23], 3);                                         // [b_alpha, b_r, b_g, b_b]
-    pk.btiles(params[19], 256, 8);                                                     // feature_linear.bias
-    pk.btiles(params[17], 128, 4);                                                     // views_linears.0.bias
+    pk.btiles(fold + 128 * SW_FOLD_LD, 128, 4);                                        // b_vf = Wv[:, :256] . b_f + b_v
     pk.vecs(params[22], 3, 128);                                                       // rgb_linear.weight
     if (!pk.rc && pk.b != dst + SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS) return sw_fail(SWNERF_E_ARG, "pack_net_x3: bias layout mismatch");
     return pk.flush();

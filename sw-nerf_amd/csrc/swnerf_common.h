@@ -117,16 +117,16 @@
 #define SW_NVBWD_FLOATS (SW_DBWD_W_FLOATS + SW_NVBWD_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
 // ---- bf16x3 path (mlp_core_x3.h): canonical net as k-block-major groups of [A_hi 1 KiB][A_lo 1 KiB], 8 groups per chunk --
-// groups: L0 8x4 | L1..L4 8x16 each | L5 8x20 (h then gamma(x)) | L6 L7 8x16 | FEAT 8x16 | VIEWS 4x18 (feature then gamma(d))
-#define SW_X3_CANON_GROUPS (32 + 4 * 128 + 160 + 2 * 128 + 128 + 72)
+// groups: L0 8x4 | L1..L4 8x16 each | L5 8x20 (h then gamma(x)) | L6 L7 8x16 | VIEWS 4x18 (h7 through the folded W_vf, then gamma(d))
+#define SW_X3_CANON_GROUPS (32 + 4 * 128 + 160 + 2 * 128 + 72)
 #define SW_X3_CANON_CHUNKS (SW_X3_CANON_GROUPS / 8)
 #define SW_X3_TAIL_CHUNKS 8       // the stream ends with a copy of its first chunks (>= ring slots)
 #define SW_X3_CHUNK_FLOATS 4096
 #define SW_X3_W_FLOATS ((SW_X3_CANON_CHUNKS + SW_X3_TAIL_CHUNKS) * SW_X3_CHUNK_FLOATS)
-// blob: [weight stream + tail][the canonical bias tiles in the UNFOLDED order: the bf16x3 core still runs feature_linear as
-// its layer 8 (mlp_core_x3.h) - L0 8 | L1-4 32 | L5 8 | L6-7 16 | alpha_linear.weight 8 + 1 head-bias tile | FEAT 8 | VIEWS 4 |
-// rgb_linear.weight 12; written by sw_pack_canon_bias_unfolded (pack_kernels.hip)]
-#define SW_X3_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 8 + 4 + 12)
+// blob: [weight stream + tail][the canonical bias tiles in this core's consumption order - L0 8 | L1-4 32 | L5 8 | L6-7 16 |
+// alpha_linear.weight 8 + 1 head-bias tile | b_vf 4 (feature_linear folded into the view layer) | rgb_linear.weight 12;
+// written by sw_pack_canon_bias_x3 (pack_kernels.hip)]
+#define SW_X3_CANON_BIAS_TILES (8 + 32 + 8 + 16 + 8 + 1 + 4 + 12)
 #define SW_X3_FLOATS (SW_X3_W_FLOATS + SW_X3_CANON_BIAS_TILES * SW_BIAS_TILE_FLOATS)
 
 // D-NeRF: deformation net groups D0 8x6 (gamma(x) then gamma(t)) | D1..D4 | D5 8x20 | D6 D7, then the canonical groups

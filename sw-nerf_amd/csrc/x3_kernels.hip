@@ -17,7 +17,7 @@
 
 enum { XK_TRUNK = 0, XK_POS0 = 1, XK_POS1 = 2, XK_DIR = 3, XK_TIME = 4 };
 
-int sw_pack_canon_bias_unfolded(const float* const* params, float* dst, hipStream_t st);   // pack_kernels.hip
+int sw_pack_canon_bias_x3(const float* const* params, const float* fold, float* dst, hipStream_t st);   // pack_kernels.hip
 
 struct X3Seg {
     const float* W; int out_dim, in_dim, NT, KB;
@@ -92,16 +92,16 @@ struct X3Packer {
             }
         }
     }
-    void canon(const float* const* params) {
+    // fold: the fp32 blob's folded view layer [128][SW_FOLD_LD] = [Wv[:, :256] . W_f | Wv[:, 256:]] (feature_linear has no activation)
+    void canon(const float* const* params, const float* fold) {
         trunk(params, false);
         trunk_blocks(0);
-        seg(params[18], 256, 256, 8, 16);                                           // feature_linear
         kt[16] = kt[17] = XK_DIR; kb0[16] = kb0[17] = 256;
-        seg(params[16], 128, 256 + Cdir, 4, 18);                                    // views_linears.0 = [feature | gamma(d)]
+        seg(fold, 128, SW_FOLD_LD, 4, 18);                                          // views_linears.0 . feature_linear on [h7 | gamma(d)]
     }
 };
 
-// packed_fp32: the blob swnerf_pack_net made for the same kind and tensors (its bias tiles are copied)
+// packed_fp32: the blob swnerf_pack_net made for the same kind and tensors (its deformation bias tiles and its folded view layer are used)
 extern "C" int swnerf_pack_net_x3_kind(int kind, const float* const* params, int L_pos, int L_dir, int L_time,
                                        const float* packed_fp32, float* packed_x3, void* stream) {
     if (!params || !packed_fp32 || !packed_x3) return sw_fail(SWNERF_E_ARG, "pack_net_x3: NULL pointer");
@@ -118,26 +118,27 @@ extern "C" int swnerf_pack_net_x3_kind(int kind, const float* const* params, int
     if (kind == SWNERF_NET_DNERF) {
         X3Packer pk{st, reinterpret_cast<unsigned*>(packed_x3), L_pos, L_dir, L_time, 3 * (1 + 2 * L_pos), 3 * (1 + 2 * L_dir), 1 + 2 * L_time, 0, {0}, {0}};
         pk.trunk(params + 24, true);                                                // deformation net, then the canonical net
-        pk.canon(params);
+        pk.canon(params, packed_fp32 + SW_DNERF_A_FLOATS + SW_CANON_FOLD_OFFSET);
         if (pk.rc) return pk.rc;
         if (pk.w != reinterpret_cast<unsigned*>(packed_x3) + (size_t)(SW_X3_DEFORM_CHUNKS + SW_X3_CANON_CHUNKS) * SW_X3_CHUNK_FLOATS)
             return sw_fail(SWNERF_E_ARG, "pack_net_x3: internal layout mismatch");
         if ((rc = copy(reinterpret_cast<float*>(pk.w), packed_x3, (size_t)SW_X3_TAIL_CHUNKS * SW_X3_CHUNK_FLOATS, "pack_net_x3 tail copy"))) return rc;
-        // bias tiles: the deformation net's as in the fp32 blob, the canonical net's in the unfolded order (this core runs feature_linear)
+        // bias tiles: the deformation net's as in the fp32 blob, the canonical net's in this core's order (b_vf behind the head-bias tile)
         // (the fp32 blob's bias stream starts with the 4 b_vf tiles of its per-ray DIR prefix; the deformation net's follow)
         if ((rc = copy(packed_x3 + SW_X3_DNERF_W_FLOATS, packed_fp32 + SW_DNERF_W_FLOATS + SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS,
                        (size_t)SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, "pack_net_x3 bias copy"))) return rc;
-        if ((rc = sw_pack_canon_bias_unfolded(params, packed_x3 + SW_X3_DNERF_W_FLOATS + SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, st))) return rc;
+        if ((rc = sw_pack_canon_bias_x3(params, packed_fp32 + SW_DNERF_A_FLOATS + SW_CANON_FOLD_OFFSET,
+                                        packed_x3 + SW_X3_DNERF_W_FLOATS + SW_DEFORM_BIAS_TILES * SW_BIAS_TILE_FLOATS, st))) return rc;
         packed_x3 += SW_X3_DNERF_A_FLOATS;                                          // then the canon-only blob (t == 0 branch)
         packed_fp32 += SW_DNERF_A_FLOATS;
     }
     X3Packer pk{st, reinterpret_cast<unsigned*>(packed_x3), L_pos, L_dir, L_time, 3 * (1 + 2 * L_pos), 3 * (1 + 2 * L_dir), 1 + 2 * L_time, 0, {0}, {0}};
-    pk.canon(params);
+    pk.canon(params, packed_fp32 + SW_CANON_FOLD_OFFSET);
     if (pk.rc) return pk.rc;
     if (pk.w != reinterpret_cast<unsigned*>(packed_x3) + (size_t)SW_X3_CANON_CHUNKS * SW_X3_CHUNK_FLOATS)
         return sw_fail(SWNERF_E_ARG, "pack_net_x3: internal layout mismatch");
     if ((rc = copy(reinterpret_cast<float*>(pk.w), packed_x3, (size_t)SW_X3_TAIL_CHUNKS * SW_X3_CHUNK_FLOATS, "pack_net_x3 tail copy"))) return rc;
-    return sw_pack_canon_bias_unfolded(params, packed_x3 + SW_X3_W_FLOATS, st);
+    return sw_pack_canon_bias_x3(params, packed_fp32 + SW_CANON_FOLD_OFFSET, packed_x3 + SW_X3_W_FLOATS, st);
 }
 
 extern "C" int swnerf_pack_net_x3(const float* const* params, int L_pos, int L_dir, const float* packed_canon, float* packed_x3, void* stream) {
