@@ -15,6 +15,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
 // raw2outputs backward, one wave per ray.  With c = sigmoid(rgb), e = exp(-relu(sigma)*dist),
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(512, 4) gemm_tn_kernel(GemmTN P) {
 // 4 LDS reads per 4 MFMAs.
 #define GD_SLAB 32
 #ifndef GD_RIDER_UNR
-#define GD_RIDER_UNR 4                    // (8 measures the same, 16 spills: profiles/r04/gemm_exp.md)
+#define GD_RIDER_UNR 4                    // k-pairs unrolled in an item with a rider
 #endif
 #define GD_BUF_FLOATS (2 * GD_SLAB * 256)            // A slab then B slab
 #define GD_B2_FLOATS (GD_SLAB * 64)                  // optional second B operand, <= 64 columns
@@ -363,13 +364,19 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b][r] = 0.f;
     }
-    float bs0 = 0.f, bs1 = 0.f, bs3 = 0.f;
+    f32x2 bs01 = {0.f, 0.f};                                 // column sums of this lane's two A columns
+    float bs3 = 0.f;
     const bool do_bias = P.bias != nullptr && i0 == 0;       // (w and P.bias are wave-uniform: a scalar branch)
     const int ot2 = 32 * (w & 7), it2 = 32 * (w >> 3);       // B2 rider: this wave's 32 x 32 tile of C2
     issue(0);
     if (HB2 || HA2) { rider_load(0); rider_store(0); }
     // -DGEMM_EXP_* (tools/experiments/gemm/build.sh; timing experiments, WRONG results, never the shipped library):
     // NOBARRIER no slab barrier | NODMA only the first two slabs are ever fetched | NOVALU no row masks / bias sums | NOEPI no atomics
+    // The WHOLE slab loop once per bias role (the test in front of it, not inside: with two copies of the unrolled steps inside the
+    // loop hipcc keeps accumulator tiles alive across both and spills 150+ registers at this kernel's 128-register budget - as in
+    // narrow5_kernel).  Both copies execute the same barriers.
+    auto slabs = [&](auto bias_) {
+    constexpr bool BIAS = decltype(bias_)::value;
 #pragma nounroll
     for (int sl = 0; sl < nslab; ++sl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
@@ -386,11 +393,21 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
             __syncthreads();
         }
         const float* Ab = Abw;
-        const float* As = Ab + o0 + i;
-        const float* Bs = Ab + GD_SLAB * 256 + i0 + i;
-        // operands of k-pair s+1 are read while the MFMAs of k-pair s run; the first reads go out BEFORE the next
-        // slab's DMA is issued, so that its scalar address work hides under their LDS latency
-        float a0 = As[hp * 256], a1 = As[hp * 256 + 32], b0 = Bs[hp * 256], b1 = Bs[hp * 256 + 32];
+        // The wave's 64 x 64 block of C is FOUR INTERLEAVED tiles - rows o0 + 2m + {0,1} x columns i0 + 2n + {0,1} - so that lane i's two
+        // A operands of a k-pair (columns o0 + 2i, o0 + 2i + 1 of one row) and its two B operands are ONE ds_read_b64 each, offset in
+        // the instruction: no address arithmetic sits between the MFMAs (tiles of 32 adjacent columns are 128 B apart - a ds_read2_b32
+        // reaches 1 KiB, i.e. two v_add_u32 per k-pair on all 16 waves: 7 % of the launch, profiles/r04/gemm_exp.md), and the bias column
+        // sums are one v_pk_add_f32.  Operands of k-pair s+1 are read while the MFMAs of k-pair s run; the first reads go out BEFORE the
+        // next slab's DMA is issued, so that its scalar address work hides under their LDS latency.
+        const f32x2* A2p = reinterpret_cast<const f32x2*>(Ab + o0 + 2 * i + hp * 256);
+        const f32x2* B2p = reinterpret_cast<const f32x2*>(Ab + GD_SLAB * 256 + i0 + 2 * i + hp * 256);
+        f32x2 a = A2p[0], b = B2p[0];
+        // rider operands: per-slab lane bases as opaque float indices into the LDS array (the B2 / A2 slabs lie beyond the 64 KiB an
+        // instruction offset reaches: left to itself hipcc re-adds the 128 KiB constant before every read)
+        int e1o = (int)(b2s - gd_lds) + (sl & 1) * GD_B2_FLOATS + hp * 64 + it2 + i;
+        int f0o = (int)(a2s - gd_lds) + (sl & 1) * GD_A2_FLOATS + hp * 32 + i;
+        if (HB2) asm("" : "+v"(e1o));
+        if (HA2) asm("" : "+v"(f0o));
         __builtin_amdgcn_sched_barrier(0);
 #ifdef GEMM_EXP_NODMA
         if (sl + 1 < 2) {
@@ -400,63 +417,59 @@ __device__ __forceinline__ void gemm_dma_body(const GemmFused& F, const int slic
             issue(sl + 1);
             if (HB2 || HA2) rider_load(sl + 1);
         }
-        constexpr int UNR = (HB2 || HA2) ? GD_RIDER_UNR : GD_SLAB / 2;    // a rider's extra tile leaves fewer registers for the unroll
+        {
+            constexpr int UNR = (HB2 || HA2) ? GD_RIDER_UNR : GD_SLAB / 2;    // a rider's extra tile leaves fewer registers for the unroll
 #pragma unroll UNR
-        for (int s = 0; s < GD_SLAB / 2; ++s) {
-            const int row = 2 * s + hp;
-#ifdef GEMM_EXP_OLDMASK                                       // round 3's form, for the A/B in profiles/r04/gemm_exp.md
-            const bool ok = row < valid;
-            const float c0 = ok ? a0 : 0.f, c1 = ok ? a1 : 0.f, d0 = b0, d1 = b1;
-#else
-            const float c0 = a0, c1 = a1, d0 = b0, d1 = b1;   // (rows past the slice are zero on the A side: see above)
-#endif
-            float e0 = 0.f, e1 = 0.f, f0 = 0.f, f1 = 0.f;
-            if (HB2) {                                        // A columns of this wave's C2 tile x B2 columns
-                e0 = Ab[row * 256 + ot2 + i];
-                e1 = b2s[(sl & 1) * GD_B2_FLOATS + row * 64 + it2 + i];
-            }
-            if (HA2) {                                        // A2 columns (zero padded) x B columns 32(w&7).. (waves 8..15
-                f0 = a2s[(sl & 1) * GD_A2_FLOATS + row * 32 + i];      // duplicate 0..7 rather than branch; only 0..7 write)
-                f1 = Ab[GD_SLAB * 256 + row * 256 + 32 * (w & 7) + i];
-            }
-            {                                                 // (the last iteration reads 2 rows past the slab: the next
-                const int nr = (min(row + 2, GD_SLAB - 1)) * 256;   // buffer region or its own last row - harmless, unused)
-                a0 = As[nr]; a1 = As[nr + 32]; b0 = Bs[nr]; b1 = Bs[nr + 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < GD_SLAB / 2; ++s) {
+                const int row = 2 * s + hp;
+                const f32x2 c = a, d = b;                     // (rows past the slice are zero on the A side: see above)
+                float e0 = 0.f, e1 = 0.f, f0 = 0.f, f1 = 0.f;
+                if (HB2) {                                    // A columns of this wave's C2 tile x B2 columns
+                    e0 = Ab[row * 256 + ot2 + i];
+                    e1 = gd_lds[e1o + 2 * s * 64];
+                }
+                if (HA2) {                                    // A2 columns (zero padded) x B columns 32(w&7).. (waves 8..15
+                    f0 = gd_lds[f0o + 2 * s * 32];                         // duplicate 0..7 rather than branch; only 0..7 write)
+                    f1 = Ab[GD_SLAB * 256 + row * 256 + 32 * (w & 7) + i];
+                }
+                {                                             // (the last k-pair reads the slab's last two rows again: harmless, unused)
+                    const int nr = min(2 * s + 2, GD_SLAB - 2) * 128;
+                    a = A2p[nr]; b = B2p[nr];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #ifndef GEMM_EXP_NOVALU
-#ifdef GEMM_EXP_OLDMASK
-            bs0 += c0; bs1 += c1;
-#else
-            if (do_bias) { bs0 += c0; bs1 += c1; }            // wave-uniform: only the four waves of the first column block own bias entries
+                if (BIAS) asm("v_pk_add_f32 %0, %0, %1" : "+v"(bs01) : "v"(c));    // (hipcc splits a two-float vector add into two v_add_f32)
 #endif
-#endif
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, d1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d0, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, d1, acc[3], 0, 0, 0);
-            if (HB2) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, e1, accb, 0, 0, 0);
-            if (HA2) { acca = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, f1, acca, 0, 0, 0); bs3 += f0; }
-            __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[0], d[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[0], d[1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[1], d[0], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(c[1], d[1], acc[3], 0, 0, 0);
+                if (HB2) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(e0, e1, accb, 0, 0, 0);
+                if (HA2) { acca = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, f1, acca, 0, 0, 0); bs3 += f0; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if ((HB2 || HA2) && sl + 1 < nslab) rider_store(sl + 1);   // visible after the next barrier
     }
+    };
+    if (do_bias) slabs(std::true_type{}); else slabs(std::false_type{});   // wave-uniform: only the four waves of the first column block own bias entries
 #ifdef GEMM_EXP_NOEPI
-    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + accb[0] + acca[0] + bs0 + bs1 + bs3 != 12345.678f) return;
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + accb[0] + acca[0] + bs01[0] + bs01[1] + bs3 != 12345.678f) return;
 #endif
-    // C/D map: register r of lane (j = i, h = hp) of tile (oa, ib) is row o0 + 32 oa + frow(r,h), column i0 + 32 ib + j
+    // C/D map: register r of lane (j = i, h = hp) of tile (oa, ib) is row o0 + 2 frow(r,h) + oa, column i0 + 2 j + ib (interleaved tiles)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int col = i0 + 32 * (b & 1) + i;
+        const int col = i0 + 2 * i + (b & 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int o = o0 + 32 * (b >> 1) + sw_frow(r, hp);
+            const int o = o0 + 2 * sw_frow(r, hp) + (b >> 1);
             atomicAdd(P.C + (size_t)o * P.ldc + col, acc[b][r]);
         }
     }
     if (do_bias) {
+        float bs0 = bs01[0], bs1 = bs01[1];
         bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
-        if (hp == 0) { atomicAdd(P.bias + o0 + i, bs0); atomicAdd(P.bias + o0 + 32 + i, bs1); }
+        if (hp == 0) { atomicAdd(P.bias + o0 + 2 * i, bs0); atomicAdd(P.bias + o0 + 2 * i + 1, bs1); }
     }
     if (HB2 && it2 + i < F.Ni2) {
 #pragma unroll
@@ -706,8 +719,9 @@ extern "C" int swnerf_gemm_tn_group(const swnerf_gemm_item* items, int n_items, 
         F.g.A = q.A; F.g.lda = q.lda; F.g.No = 256; F.g.B = q.B; F.g.ldb = q.ldb; F.g.Ni = 256; F.g.C = q.C; F.g.ldc = q.ldc; F.g.bias = q.bias; F.g.M = M;
         F.B2 = q.B2; F.ldb2 = q.ldb2; F.Ni2 = q.Ni2; F.C2 = q.C2; F.ldc2 = q.ldc2;
         F.A2 = q.A2; F.lda2 = q.lda2; F.No2 = q.No2; F.C3 = q.C3; F.ldc3 = q.ldc3; F.bias3 = q.bias3;
-        static const int rider_w = getenv("SWNERF_GG_RIDER_W") ? atoi(getenv("SWNERF_GG_RIDER_W")) : 6;
-        weight[G.n] = (q.B2 || q.A2) ? rider_w : 4;         // 5 MFMAs per 4 and a shorter unroll: 1.2-1.3x alone, 6 : 4 measured best in a group
+        static const int rider_w = getenv("SWNERF_GG_RIDER_W") ? atoi(getenv("SWNERF_GG_RIDER_W")) : 12;
+        static const int plain_w = getenv("SWNERF_GG_PLAIN_W") ? atoi(getenv("SWNERF_GG_PLAIN_W")) : 8;
+        weight[G.n] = (q.B2 || q.A2) ? rider_w : plain_w;         // 5 MFMAs per 4 and a shorter unroll: 1.2-1.3x alone, 6 : 4 measured best in a group
         any_b2 |= q.B2 != nullptr; any_a2 |= q.A2 != nullptr;
         ++G.n;
     }

@@ -99,27 +99,36 @@ __global__ void __launch_bounds__(256) pack_plan_kernel(PackPlan P) {
 // b_vf[u] = sum_o Wv[u][o] b_f[o] + b_v[u].  Double accumulation, one rounding: the folded row is as close to the exact
 // product as a float can be (the two-layer form rounds `feature` AND the second product).  Block u, thread i.
 // Reference: model.py:49-53 (feature_linear -> cat -> views_linears[0], no activation in between).
-__global__ void __launch_bounds__(256) fold_views_kernel(const float* Wv, int ldv, const float* bv, const float* Wf, const float* bf,
-                                                         int Cdir, float* fold) {
+__global__ void __launch_bounds__(1024) fold_views_kernel(const float* Wv, int ldv, const float* bv, const float* Wf, const float* bf,
+                                                          int Cdir, float* fold) {
+    // one output row u per workgroup; the 256-term sum is dealt over four quarters of the workgroup (a training step folds four
+    // times - two nets, forward and backward stream - and a 256-long dependent fp64 chain per thread cost 24 us a time)
     __shared__ float wrow[256];
-    const int u = blockIdx.x, i = threadIdx.x;
-    wrow[i] = Wv[(size_t)u * ldv + i];
+    __shared__ double part[4][256];
+    __shared__ double bprod[256];
+    const int u = blockIdx.x, i = threadIdx.x & 255, q = threadIdx.x >> 8;
+    if (q == 0) wrow[i] = Wv[(size_t)u * ldv + i];
     __syncthreads();
     double acc = 0.0;
-    for (int o = 0; o < 256; ++o) acc += (double)wrow[o] * (double)Wf[(size_t)o * 256 + i];
+    for (int o = 64 * q; o < 64 * q + 64; ++o) acc += (double)wrow[o] * (double)Wf[(size_t)o * 256 + i];
+    part[q][i] = acc;
+    if (q == 1) bprod[i] = (double)wrow[i] * (double)bf[i];
+    __syncthreads();
     float* row = fold + (size_t)u * SW_FOLD_LD;
-    row[i] = (float)acc;
-    if (i < SW_FOLD_LD - 256) row[256 + i] = i < Cdir ? Wv[(size_t)u * ldv + 256 + i] : 0.f;
-    if (i == 0) {
-        double b = (double)bv[u];
-        for (int o = 0; o < 256; ++o) b += (double)wrow[o] * (double)bf[o];
-        fold[(size_t)128 * SW_FOLD_LD + u] = (float)b;
+    if (q == 0) {
+        row[i] = (float)(((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]);
+        if (i < SW_FOLD_LD - 256) row[256 + i] = i < Cdir ? Wv[(size_t)u * ldv + 256 + i] : 0.f;
+    } else if (q == 1 && i < 64) {                         // b_vf: 64 lanes x 4 terms, then a wave reduction (fp64 throughout, one rounding)
+        double b = ((bprod[i] + bprod[64 + i]) + bprod[128 + i]) + bprod[192 + i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
+        if (i == 0) fold[(size_t)128 * SW_FOLD_LD + u] = (float)(b + (double)bv[u]);
     }
 }
 
 // views_linears.0 . feature_linear of the net `params` (canonical order) -> fold [SW_FOLD_FLOATS]
 static int fold_views(const float* const* params, int Cdir, float* fold, hipStream_t st) {
-    hipLaunchKernelGGL(fold_views_kernel, dim3(128), dim3(256), 0, st, params[16], 256 + Cdir, params[17], params[18], params[19], Cdir, fold);
+    hipLaunchKernelGGL(fold_views_kernel, dim3(128), dim3(1024), 0, st, params[16], 256 + Cdir, params[17], params[18], params[19], Cdir, fold);
     return sw_check(hipGetLastError(), "pack_net fold launch");
 }
 

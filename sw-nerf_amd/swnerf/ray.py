@@ -142,6 +142,7 @@ class _Raw2Outputs(torch.autograd.Function):
         ctx.save_for_backward(raw, z_vals, rays_d, noise if noise is not None else torch.empty(0, device=dev))
         ctx.white = bool(white_bkgd)
         ctx.has_noise = noise is not None
+        ctx.set_materialize_grads(False)       # an output the loss does not use arrives as None (no zero fill, no read of zeros in the kernel)
         return rgb, disp, acc, w, depth
 
     @staticmethod

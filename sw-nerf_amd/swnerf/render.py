@@ -276,6 +276,7 @@ class _FusedPassTrain(torch.autograd.Function):
         ctx.has_noise, ctx.noview, ctx.out_ch = noise is not None, noview, out_ch
         ctx.save_for_backward(rb, z, raw, act, bits, xs, noise if noise is not None else new(0), *params)
         ctx.mark_non_differentiable(z_fine, z_std)
+        ctx.set_materialize_grads(False)       # an output the loss does not use arrives as None (no zero fill, no read of zeros in the kernel)
         # raw is an output as well (retraw=True is what the reference's train() passes, nerf/run.py:685): a gradient
         # arriving on it is added to d raw in the backward kernel
         return rgb, disp, acc, z_fine, z_std, raw

@@ -114,6 +114,7 @@ class _FusedPassTrainDnerf(torch.autograd.Function):
         ctx.has_noise = noise is not None
         ctx.save_for_backward(rb, z, raw, dx, act, bits, xs, act_d, bits_d, xs_d, noise if noise is not None else new(0), *params)
         ctx.mark_non_differentiable(z)
+        ctx.set_materialize_grads(False)       # an output the loss does not use arrives as None (no zero fill, no read of zeros in the kernel)
         return rgb, disp, acc, dx, z, raw
 
     @staticmethod

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/timeline; mkdir -p $OUT; rm -rf $OUT/trace_$tag; cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$tag -- python3 "$@" > $OUT/$tag.log 2>&1 || { echo "trace failed"; tail -5 $OUT/$tag.log; exit 1; }
 f=$(find $OUT/trace_$tag -name '*kernel_trace.csv' | head -1)
-python3 - "$f" "${FWD_PER_STEP:-2}" > $OUT/$tag.md <<'PY'
+FULL=$OUT/${tag}_full.txt python3 - "$f" "${FWD_PER_STEP:-2}" > $OUT/$tag.md <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 per = int(sys.argv[2])
@@ -23,6 +23,15 @@ for r in rows[i0:i1]:
     if e - s >= 20000:
         print(f"| {s / 1e3:.0f} | {e / 1e3:.0f} | {(e - s) / 1e3:.0f} | {r.get('Queue_Id', '?')} | {r['Kernel_Name'].split('(')[0][-60:]} |")
 print(f"\nstep = {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.0f} us from first forward launch to the next step's")
+import os
+if os.environ.get("FULL"):                 # every launch of the step with the idle gap in front of it -> <tag>_full.txt
+    with open(os.environ["FULL"], "w") as fo:
+        prev = None
+        for r in rows[i0:i1 + 1]:
+            s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+            gap = 0 if prev is None else s - prev
+            prev = max(e, prev or 0)
+            fo.write(f"{s / 1e3:9.1f} {(e - s) / 1e3:8.1f} gap {gap / 1e3:6.1f}  {r['Kernel_Name'].split('(')[0][-70:]}\n")
 # the small launches (< 20 us) of the step, and how long the GPU sat idle between kernels
 from collections import defaultdict
 small = defaultdict(lambda: [0, 0])
