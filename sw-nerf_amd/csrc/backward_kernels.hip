@@ -979,7 +979,9 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
 #pragma nounroll
         for (int sl = 0; sl < nslab; ++sl) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of slab sl has landed ...
+#ifndef N5_EXP_NOBARRIER                                          // (-DN5_EXP_*: timing experiments, WRONG results - tools/probe_n5_exp.py)
             __syncthreads();                                      // ... everyone's has; and everyone is done with slab sl-1
+#endif
             const int valid = mlen - sl * N5_SLAB;
             const int buf = (sl & 1) * N5_BUF;
             if (valid < N5_SLAB) {
@@ -990,8 +992,14 @@ __global__ void __launch_bounds__(1024) narrow5_kernel(Narrow5 P) {
                 if (t < (N5_SLAB - valid) * 4) n5_lds[buf + N5_A2 + valid * 4 + t] = 0.f;
                 __syncthreads();
             }
+#ifdef N5_EXP_NODMA
+            if (sl + 1 < 2) issue(sl + 1);
+#else
             if (sl + 1 < nslab) issue(sl + 1);
+#endif
+#ifndef N5_EXP_NOMFMA
             n5_slab<AP, BP, NA, NB>(n5_lds, buf + asrc + i + hp * AP, buf + bsrc + i + hp * BP, acol, bcol, acc, bs0, bs2, bias);
+#endif
         }
     };
     using std::integral_constant;

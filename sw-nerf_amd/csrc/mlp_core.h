@@ -174,7 +174,9 @@ __device__ __forceinline__ void seg_steps(f32x16 (&out)[NT], const f32x16 (&kin)
             if constexpr (S % every == every - 1 && S / every < total) {
                 constexpr int idx = S / every, n2 = idx / 4, g = idx % 4;
                 const f32x4 v = {kin[n2][4 * g], kin[n2][4 * g + 1], kin[n2][4 * g + 2], kin[n2][4 * g + 3]};
+#ifndef TRAIN_EXP_NOSTORE
                 *reinterpret_cast<f32x4*>(ss.sp + 32 * n2 + 8 * g) = v;
+#endif
             }
             if constexpr (S == 1) {
                 if (ss.mp) *reinterpret_cast<f32x4*>(ss.mp) = ss.mv;      // wave-uniform condition
@@ -213,6 +215,9 @@ __device__ __forceinline__ void seg_mfma(f32x16 (&out)[NT], const f32x16 (&kin)[
 template <int NT>
 __device__ __forceinline__ f32x4 relu_bits(const f32x16 (&t)[NT]) {
     unsigned m[4] = {0u, 0u, 0u, 0u};
+#ifdef TRAIN_EXP_NOBITS                                  // (timing experiment, WRONG gradients: tools/experiments/train/build.sh)
+    return f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
