@@ -442,6 +442,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     }
 #endif
     if (!resample || ghost) return;
+#ifdef SW_PROBE
+    const unsigned long long probe_rs0 = sw_clock();
+#endif
 
     // ---- sample_pdf (ray.py:96-153) on bins = mid-points, weights[1:-1]; z_std; then sort (nerf/run.py:396-400, 416) as a rank
     // merge - the wave-level routines of resample.h, shared with the standalone op
@@ -453,5 +456,11 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         if (lane == 0) a.z_std[ray] = sd;
     }
     wave_rank_merge(zc, S, P.sort_s, srt, Ni, P.sort_n, a.z_fine + ray * (S + Ni), lane);
+#ifdef SW_PROBE
+    if (a.weights && lane == 0) {                    // [9] the resampling tail, [10] compositing epilogue .. its start
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.weights + ray * S);
+        o[9] = sw_clock() - probe_rs0;
+    }
+#endif
 }
 
