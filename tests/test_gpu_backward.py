@@ -245,6 +245,38 @@ def test_fused_training_pass_matches_op_path_and_autograd(dev, monkeypatch):
     ret["rgb_map"].sum().backward()
 
 
+@pytest.mark.gpu
+def test_fused_training_pass_with_unused_outputs(dev, monkeypatch):
+    """A loss that uses ONE output of the fused pass: the gradients of the others arrive as None (set_materialize_grads(False) - no
+    zero fills, NULL pointers into the backward kernel, csrc/train_kernels.hip).  acc_map alone (no gradient on rgb_map at all) and
+    disp_map alone, fused against the op path."""
+    import swnerf.embedder as embedder, swnerf.render as render
+    sd_c, _ = cases.weights_static()
+    embed_fn, _ = embedder.get_embedder(10, 3, 0)
+    embeddirs_fn, _ = embedder.get_embedder(4, 3, 0)
+    q = lambda inputs, viewdirs, network_fn: render.run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
+                                                                embeddirs_fn=embeddirs_fn, netchunk=1024 * 64)
+    g = cases.g7_inputs(n=21, seed=12)
+    rb = O.make_ray_batch(T(g["rays_o"]), T(g["rays_d"]), 2., 6.).to(dev)
+    wa = T(np.random.default_rng(8).standard_normal(21).astype(np.float32)).to(dev)
+    for key in ("acc_map", "disp_map"):
+        grads = []
+        for op_path in (False, True):
+            if op_path:
+                monkeypatch.setenv("SWNERF_TRAIN_OP_PATH", "1")
+            else:
+                monkeypatch.delenv("SWNERF_TRAIN_OP_PATH", raising=False)
+            net = _static_net(dev, sd_c)
+            ret = render.render_rays(rb, net, q, 48, N_importance=0, white_bkgd=True)
+            (ret[key].nan_to_num(0.0) * wa).mean().backward()
+            grads.append({k: p.grad for k, p in net.named_parameters()})
+        for k in grads[0]:
+            assert grads[0][k] is not None, k
+            r = grads[1][k].double().cpu().numpy()
+            d = np.abs(grads[0][k].double().cpu().numpy() - r).max()
+            assert d <= 2e-6 * max(np.abs(r).max(), 1e-12), f"{key} only, {k}: fused vs op path {d:.3e}"
+
+
 def _dnerf_net(dev, sd_np):
     import swnerf.embedder as embedder, swnerf.model as model
     embed_fn, _ = embedder.get_embedder(10, 3, 0)
