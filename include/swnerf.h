@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SWNERF_VERSION 109
+#define SWNERF_VERSION 110
 
 #define SWNERF_E_ARG      (-1)   /* bad size / NULL pointer / unsupported shape */
 #define SWNERF_E_UNSUPP   (-2)   /* valid in the reference, not built here (message says what) */
@@ -58,7 +58,11 @@ const char* swnerf_last_error(void);
  * activation, so views_linears.0(cat[feature_linear(h), dirs]) = [Wv[:, :256] W_f | Wv[:, 256:]] . cat[h, dirs] + (Wv[:, :256] b_f
  * + b_v); the product is formed in double and rounded once): the kernels run ONE 128 x (256 + C_dir) layer where the
  * reference runs a 256 x 256 and a 128 x (256 + C_dir) one - 11 % fewer MFMAs per row, same function.  The caller's
- * tensors, their gradients (swnerf_feature_finish) and checkpoints are untouched. */
+ * tensors, their gradients (swnerf_feature_finish) and checkpoints are untouched.
+ * Since version 110 a SWNERF_NET_DNERF blob carries layer 0 of the deformation net (model.py:129: _time.0 on cat[gamma(x),
+ * gamma(t)]) as two segments - bias + the gamma(t) columns, then the gamma(x) columns: the fused passes evaluate the first ONCE PER
+ * RAY (one frame time per ray, run_dnerf.py:354-360), the per-row entry points (swnerf_mlp_forward, deform_forward_train) in line.
+ * Same function, same blob size; blobs are not interchangeable across versions (they are made per process, never stored). */
 size_t swnerf_packed_floats(int kind);
 int swnerf_pack_net(int kind, const float* const* params /*HOST*/, int L_pos, int L_dir,
                     int L_time, float* packed, void* stream);

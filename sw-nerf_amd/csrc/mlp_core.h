@@ -405,11 +405,12 @@ __device__ __forceinline__ void tile_fetch(const float* lds_tile, int lane, f32x
 // stores of layer 0, whose B operand they are.
 // NOHEAD: stop after layer 7 (`in` = relu(h7)); the caller applies its own head (output_linear of a net without view
 // directions, head_valu_rt).
-template <bool DNERF, bool TRAIN = false, bool XS = false, bool NOHEAD = false>
+// TB (D-NeRF, fused passes): layer 0 of the deformation pass starts from the per-ray TIME tile lds_tb (see below).
+template <bool DNERF, bool TRAIN = false, bool XS = false, bool NOHEAD = false, bool TB = false>
 __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_emb, float t, bool deform_pass, int h,
                                            f32x16 (&in)[8], f32x16 (&out)[8], float (&head)[3], WStream& ws,
                                            float* act_row = nullptr, float* mask_tile = nullptr, bool store_last = false,
-                                           f32x4* mb = nullptr, float* xs_row = nullptr) {
+                                           f32x4* mb = nullptr, float* xs_row = nullptr, const float* lds_tb = nullptr) {
     const int lane_ = threadIdx.x & 63;
     emb_park(lds_emb, lane_, emb);
     f32x4 mbits = {0.f, 0.f, 0.f, 0.f};
@@ -417,11 +418,33 @@ __device__ __forceinline__ void trunk_pass(const f32x16 (&emb)[2], float* lds_em
     for (int l = 0; l < 8; ++l) {
         if (l == 0) {
             if (DNERF && deform_pass) {
-                f32x16 k3[3];
-                k3[0] = emb[0]; k3[1] = emb[1];
-                pe_time(t, h, k3[2]);
-                if (XS) seg_mfma<8, 3, SEG_BIAS, 3>(out, k3, ws, 1.f, SideStore{xs_row, nullptr, mbits});   // gamma(x), gamma(t) -> xs
-                else seg_mfma<8, 3, SEG_BIAS>(out, k3, ws);
+                // _time.0 on cat[gamma(x), gamma(t)] (model.py:129) as TWO segments of the stream: TIME (bias + the gamma(t) columns),
+                // then the gamma(x) columns on top.  TB (the fused passes: ONE time per ray): the wave has evaluated TIME
+                // once (time_bias_tile) and this tile's accumulators start from that per-ray tile - 128 MFMAs per tile less; otherwise (time
+                // per ROW: mlp_forward, the training forward of the op path): both segments here.  The same sequence of additions
+                // either way, so the two paths give the same bits.
+                if constexpr (TB) {
+                    const float* keep = ws.bias;
+                    ws.bias = lds_tb + (lane_ & 32 ? 16 : 0);
+                    if (XS) {
+                        seg_mfma<8, 2, SEG_BIAS, 2>(out, emb, ws, 1.f, SideStore{xs_row, nullptr, mbits});   // gamma(x) -> xs ...
+                        f32x16 tt;
+                        pe_time(t, h, tt);                                                                    // ... and gamma(t), on the spot
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {tt[4 * g], tt[4 * g + 1], tt[4 * g + 2], tt[4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(xs_row + 64 + 8 * g) = v;
+                        }
+                    } else {
+                        seg_mfma<8, 2, SEG_BIAS>(out, emb, ws);
+                    }
+                    ws.bias = keep;
+                } else {
+                    f32x16 k1[1];
+                    pe_time(t, h, k1[0]);
+                    seg_mfma<8, 1, SEG_BIAS>(out, k1, ws);
+                    seg_mfma<8, 2, SEG_ACC>(out, emb, ws);
+                }
             } else if (XS) {
                 seg_mfma<8, 2, SEG_BIAS, 2>(out, emb, ws, 1.f, SideStore{xs_row, nullptr, mbits});
             } else {
@@ -491,6 +514,27 @@ __device__ __forceinline__ void view_bias_tile(const f32x16& demb, float* lds_vb
         float* o = lds_vb + (lane >> 5) * 16;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {c[n][4 * g], c[n][4 * g + 1], c[n][4 * g + 2], c[n][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(o + n * SW_BIAS_TILE_FLOATS + 4 * g) = v;
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The same for the deformation net's layer 0 (D-NeRF fused passes, right behind view_bias_tile: the stream's TIME segment follows
+// its DIR prefix): tb[n][h][r] = (_time.0.bias + _time.0.weight[:, Cpos:] gamma(t))[32n + frow(r,h)], 8 tiles, once per ray.
+#define SW_TB_LDS_FLOATS (8 * SW_BIAS_TILE_FLOATS)
+__device__ __forceinline__ void time_bias_tile(float t, int h, float* lds_tb, int lane, WStream& ws) {
+    f32x16 k1[1], c[8];
+    pe_time(t, h, k1[0]);
+    seg_mfma<8, 1, SEG_BIAS>(c, k1, ws);
+    if ((lane & 31) == 0) {
+        float* o = lds_tb + (lane >> 5) * 16;
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {c[n][4 * g], c[n][4 * g + 1], c[n][4 * g + 2], c[n][4 * g + 3]};

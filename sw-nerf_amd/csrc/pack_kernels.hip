@@ -221,7 +221,18 @@ struct Packer {
         for (int i = 0; i < 8; ++i) b8[i] = 32 * i;
         const int e3[3] = {KT_POS0, KT_POS1, KT_TIME};
         const int eb[3] = {0, 0, Cpos};
-        seg(P[0], P[1], 256, Cpos + Ctime, 8, Ctime ? 3 : 2, e3, eb);           // layer 0
+        if (Ctime) {
+            // layer 0 of the deformation net on cat[gamma(x), gamma(t)] as TWO segments: TIME = bias + the gamma(t) columns (the
+            // fused passes evaluate it once per ray, mlp_core.h time_bias_tile; the per-row kernels run it in line), then the
+            // gamma(x) columns, accumulating.  A stream that begins here loops back to the gamma(x) segment: TIME is a prefix.
+            const int et[1] = {KT_TIME}, ebt[1] = {Cpos};
+            const bool first = !have_head;
+            seg(P[0], P[1], 256, Cpos + Ctime, 8, 1, et, ebt);
+            if (first) have_head = false;
+            seg(P[0], nullptr, 256, Cpos + Ctime, 8, 2, e3, eb);
+        } else {
+            seg(P[0], P[1], 256, Cpos, 8, 2, e3, eb);                           // layer 0
+        }
         for (int l = 1; l < 8; ++l) {
             if (l == 5) {                                                          // input = cat[pts_emb, h]
                 int b5[8];

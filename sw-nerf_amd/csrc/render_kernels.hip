@@ -90,6 +90,8 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
     if (rc) return rc;
     P.sort_n = 0; P.sort_s = 0;
     P.dir_steps = noview ? 0 : SW_STEPS_DIR;
+    P.time_steps = (a.kind == SWNERF_NET_DNERF && P.two_pass) ? SW_STEPS_TIME : 0;
+    P.tb_off = 0;
     size_t lds = SW_LDS_FIXED_FLOATS * sizeof(float);
     if (a.n_importance > 0) {
         if (!a.z_fine && a.n_rays != 0) return sw_fail(SWNERF_E_ARG, "render_pass: n_importance>0 needs z_fine");
@@ -104,6 +106,10 @@ extern "C" int swnerf_render_pass(const swnerf_pass_args* args, void* stream) {
         lds += 4 * SW_LDS_WAVE_FLOATS * sizeof(float);
     }
     if (a.n_rays == 0) return 0;
+    if (P.time_steps) {                          // the four waves' per-ray TIME tiles, behind everything else
+        P.tb_off = (int)(lds / sizeof(float));
+        lds += 4 * SW_TB_LDS_FLOATS * sizeof(float);
+    }
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     pass_startup_args(P, grid.x, noview ? SW_NOVIEW_STEPS : (a.kind == SWNERF_NET_DNERF && P.two_pass ? SW_DEFORM_STEPS + SW_CANON_STEPS : SW_CANON_STEPS));

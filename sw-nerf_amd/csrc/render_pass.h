@@ -36,6 +36,8 @@ struct PassDev {
     // start-up shaping of a launch (fp32 inference pass; pass_startup() below): L2 warm-up of the weight stream and a skew
     // of the waves' start.  warm_steps = 0 / skew_mode = 0 switch them off.
     int dir_steps;          // SW_STEPS_DIR when the stream starts with the per-ray DIR prefix (nets with view directions, fp32), else 0
+    int time_steps;         // SW_STEPS_TIME when the deformation net's TIME segment follows it (D-NeRF with the deformation pass), else 0
+    int tb_off;             // floats: where the four waves' per-ray TIME tiles sit in the dynamic LDS (behind everything else)
     int warm_steps;         // 1-KiB steps of the weight stream to pull into the XCD's L2 at kernel start
     int warm_blocks;        // workgroups per XCD that share the warm-up (blocks b with b < 8 * warm_blocks take part)
     int skew_mode;          // 0 none | 1 per workgroup | 2 per wave
@@ -157,6 +159,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
     float* lds_x3w = lds_ring + X3_RING_FLOATS + wv * X3Lds<DNERF>::WAVE;
     float* lds_dir = PREC ? lds_x3w : lds_emb + 2 * 16 * 64;
     float* lds_vb = lds_emb + SW_EMB_LDS_FLOATS + SW_ZSLOT_FLOATS;          // fp32, VIEWS: the per-ray init tiles of the view layer
+    const float* lds_tb = (DNERF && PREC == 0 && P.time_steps) ? lds_all + P.tb_off + wv * SW_TB_LDS_FLOATS : nullptr;   // ... of _time.0
     float* lds = PREC ? lds_all + X3Lds<DNERF>::FIXED + wv * SW_LDS_WAVE_FLOATS
                       : lds_all + PassLds<DNERF, TRAIN>::FIXED + wv * SW_LDS_WAVE_FLOATS;
     float* zc = lds;                             // [S]   depths of this pass
@@ -192,6 +195,10 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
             pe_dir(v0, v1, v2, h, demb);
             if constexpr (TRAIN) tile_park(lds_dir, lane, demb);             // the training passes also store gamma(d) per row (xs)
             view_bias_tile(demb, lds_vb, lane, ws);
+        }
+        // D-NeRF with the deformation pass: the stream's TIME segment, once per ray: _time.0.bias + its gamma(t) columns (mlp_core.h)
+        if constexpr (DNERF) {
+            if (P.time_steps) time_bias_tile(ft, h, lds_all + P.tb_off + wv * SW_TB_LDS_FLOATS, lane, ws);
         }
     }
 
@@ -249,10 +256,10 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
 #pragma nounroll
             for (int pass = 0; pass < 2; ++pass) {
                 const bool dp = pass == 0;
-                trunk_pass<true, true, true>(emb, lds_emb, ft, dp, h, in, out, head, ws,
+                trunk_pass<true, true, true, false, true>(emb, lds_emb, ft, dp, h, in, out, head, ws,
                                              dp ? P.act_d + prow * SW_ACT_LD + 4 * h : act_row,
                                              dp ? P.bits_d + tix * SW_MASK_TILE_FLOATS + lane * 4 : mask_tile, dp, &mb,
-                                             dp ? P.xs_d + prow * SW_XS_LD + 4 * h : xs_row);
+                                             dp ? P.xs_d + prow * SW_XS_LD + 4 * h : xs_row, lds_tb);
                 if (dp) {
                     const float ex = head[0], ey = head[1], ez = head[2];
                     if (live && h == 0) {
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         } else if (DNERF) {
 #pragma nounroll
             for (int pass = P.two_pass ? 0 : 1; pass < 2; ++pass) {
-                trunk_pass<true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws);
+                trunk_pass<true, false, false, false, true>(emb, lds_emb, ft, pass == 0, h, in, out, head, ws, nullptr, nullptr, false, nullptr, nullptr, lds_tb);
                 if (pass == 0) {
                     // dx = _time_out(h) (model.py:136,146-149)
                     const float ex = head[0], ey = head[1], ez = head[2];
@@ -369,7 +376,9 @@ __global__ void __launch_bounds__(256, 1) render_pass_kernel(PassDev P) {
         if (!TRAIN && PREC == 0 && VIEWS) canon_tail(in, lds_vb, rgb, ws.bias - SW_BIAS_TILE_FLOATS, ws);
         SW_STAMP(pt3);
         // back to the head of MAIN (behind the per-ray DIR prefix and its b_vf tiles)
-        if constexpr (PREC == 0) ws_rewind(ws, P.w0 + P.dir_steps * SW_STEP_FLOATS, lds_bias + (P.dir_steps ? SW_DIR_BIAS_TILES * SW_BIAS_TILE_FLOATS : 0), lane);
+        if constexpr (PREC == 0)                 // back to MAIN: behind the per-ray prefixes (DIR, and TIME with its 8 bias tiles)
+            ws_rewind(ws, P.w0 + (P.dir_steps + P.time_steps) * SW_STEP_FLOATS,
+                      lds_bias + ((P.dir_steps ? SW_DIR_BIAS_TILES : 0) + (P.time_steps ? 8 : 0)) * SW_BIAS_TILE_FLOATS, lane);
 
         // ---- raw2outputs on this tile (ray.py:155-198); both lane halves mirror each other
         const float c0 = rgb[0], c1 = rgb[1], c2 = rgb[2];

@@ -22,7 +22,8 @@
 
 // steps per segment (NT * KT * 4)
 #define SW_STEPS_EMB    64        // 8 n-tiles x 2 pos-emb k-tiles
-#define SW_STEPS_EMB_T  96        // 8 x 3 (pos emb + time emb): deformation layer 0
+#define SW_STEPS_EMB_T  96        // 8 x 1 (TIME: bias + time emb; once per RAY in the fused passes) + 8 x 2 (pos emb): deformation layer 0
+#define SW_STEPS_TIME   32        // 8 x 1
 #define SW_STEPS_TRUNK  256       // 8 x 8
 #define SW_STEPS_VIEWS  144       // 4 x 9   [h7 | gamma(d)]: the view layer where directions vary per ROW (mlp_forward, point query)
 #define SW_STEPS_DIR    16        // 4 x 1   gamma(d) alone: ONCE PER RAY in the fused passes (below)
@@ -55,7 +56,12 @@
 // the folded matrix itself rides at the end of a CANON blob: [128][SW_FOLD_LD] = [W_vf | Wv[:, 256:]] then b_vf[128]
 #define SW_FOLD_LD 288
 #define SW_FOLD_FLOATS (128 * SW_FOLD_LD + 128)
-// deformation net stream: D0 | D1..D4 | D5(trunk) D5(emb) | D6 D7 ;  bias tiles: 64 | _time_out.weight 3 x 8 | 1 head-bias tile
+// deformation net stream: TIME | D0 (gamma(x) columns, accumulating) | D1..D4 | D5(trunk) D5(emb) | D6 D7 ;
+//   bias tiles: 64 (the first 8 consumed by TIME) | _time_out.weight 3 x 8 | 1 head-bias tile.
+// _time.0's gamma(t) columns are a per-RAY constant in the fused passes (one frame time per ray, run_dnerf.py:354-360): the D-NeRF
+// blob reads DIR | TIME | MAIN = D0 .. D7 | canonical MAIN, TIME is evaluated once per ray into a per-wave LDS tile
+// (mlp_core.h time_bias_tile) and every tile's D0 accumulators start from it; a tile rewinds to D0.  Kernels whose time varies
+// per row (mlp_forward, the op path's training forward) run TIME and D0 in line.
 #define SW_DEFORM_STEPS (SW_STEPS_EMB_T + 4 * SW_STEPS_TRUNK + SW_STEPS_TRUNK + SW_STEPS_EMB + 2 * SW_STEPS_TRUNK)
 #define SW_DEFORM_BIAS_TILES (8 + 32 + 8 + 16 + 24 + 1)
 

@@ -579,6 +579,7 @@ extern "C" int swnerf_render_pass_train(const swnerf_pass_args* args, float* act
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = nullptr; P.bits_d = nullptr; P.xs_d = nullptr;
     P.sort_n = 0; P.sort_s = 0;
     P.dir_steps = noview ? 0 : SW_STEPS_DIR;
+    P.time_steps = 0; P.tb_off = 0;
     P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
     size_t lds = PassLds<false, true>::FIXED * sizeof(float);
     if (a.n_importance > 0) {
@@ -666,8 +667,10 @@ extern "C" int swnerf_render_pass_train_dnerf(const swnerf_pass_args* args, floa
     P.act = act; P.bits = bits; P.xs = xs; P.act_d = act_d; P.bits_d = bits_d; P.xs_d = xs_d;
     P.sort_n = 0; P.sort_s = 0;
     P.dir_steps = SW_STEPS_DIR;
+    P.time_steps = SW_STEPS_TIME;
+    P.tb_off = PassLds<true, true>::FIXED;       // the four waves' per-ray TIME tiles, behind everything else
     P.warm_steps = 0; P.warm_blocks = 0; P.skew_mode = 0; P.skew_unit = 0;
-    const size_t lds = PassLds<true, true>::FIXED * sizeof(float);
+    const size_t lds = (PassLds<true, true>::FIXED + 4 * SW_TB_LDS_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)((a.n_rays + 3) / 4)), block(256);
     pass_startup_args(P, grid.x, SW_DEFORM_STEPS + SW_CANON_STEPS);
     hipLaunchKernelGGL((render_pass_kernel<true, true>), grid, block, lds, (hipStream_t)stream, P);

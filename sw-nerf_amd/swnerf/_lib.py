@@ -142,8 +142,8 @@ def lib():
         if name not in ("swnerf_last_error", "swnerf_packed_floats", "swnerf_packed_bwd_floats", "swnerf_act_floats_per_row",
                         "swnerf_packed_bwd_floats_kind", "swnerf_mask_floats", "swnerf_train_rows", "swnerf_packed_bwd_noview_floats"):
             getattr(L, name).restype = c_int
-    if L.swnerf_version() != 109:
-        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 109 - rebuild it "
+    if L.swnerf_version() != 110:
+        raise RuntimeError(f"swnerf: {LIB_PATH} has version {L.swnerf_version()}, expected 110 - rebuild it "
                            "(python __graft_entry__.py)")
     _lib = L
     return L
