@@ -716,6 +716,12 @@ def test_render_rays_dnerf_golden(sw, dev, golden, nets):
     r3 = sw.render_dnerf.render_rays(_rb(g, dev, 0.5)[:64], nets["dn"], opaque, 64, N_importance=128, white_bkgd=True)
     r4 = sw.render_dnerf.render_rays(_rb(g, dev, 0.5)[:64], nets["dn"], qd, 64, N_importance=128, white_bkgd=True)
     close_mostly(r3["rgb_map"], r4["rgb_map"], atol=2e-4, frac=0.92, hard=2e-2, what="dnerf fused/unfused")
+    # without resampling the two paths run the same additions in the same order - layer 0 of the deformation net as bias, then the
+    # time terms (once per ray in the fused pass, in line in mlp_forward), then the position terms: raw and dx are the same BITS
+    r5 = sw.render_dnerf.render_rays(_rb(g, dev, 0.5)[:96], nets["dn"], opaque, 64, N_importance=0, white_bkgd=True, retraw=True)
+    r6 = sw.render_dnerf.render_rays(_rb(g, dev, 0.5)[:96], nets["dn"], qd, 64, N_importance=0, white_bkgd=True, retraw=True)
+    assert torch.equal(r5["position_delta"], r6["position_delta"]) and torch.equal(r5["raw"], r6["raw"])
+    close(r5["rgb_map"], r6["rgb_map"], atol=1e-6, what="dnerf fused/unfused rgb, no resampling")
     with pytest.raises(AssertionError):
         rb = _rb(g, dev, 0.5)[:8].clone()
         rb[3, 8] = 0.75
