@@ -72,3 +72,23 @@ def test_common_header_on_host(tmp_path):
         assert sorted(c for c in cols[64:] if c >= 0) == list(range(3 * (1 + 2 * Ld)))
     ig, dn, xld = (int(x) for x in lines[k + 5].split())
     assert dn == ig + 7 * 256 and dn % 16 == 0 and xld == 96
+
+
+def test_embed_kernel_multiply_shift_divisions_are_exact():
+    """csrc/misc_kernels.hip embed_kernel maps job j of a workgroup to (row, slot) with (j * ceil(2^24 / Q)) >> 24 in 32-bit
+    arithmetic, and slot p to (band, component) with (p * ceil(2^24 / d)) >> 24: exact - and free of 32-bit overflow - for every
+    (d <= 16, L <= 24) swnerf_embed accepts, at the rows-per-workgroup its launch picks (EMB_ROWS = 64, halved while the image exceeds 64 KB)."""
+    for d in range(1, 17):
+        d_magic = ((1 << 24) + d - 1) // d
+        for L in range(0, 25):
+            C, Q = d * (1 + 2 * L), d * (1 + L)
+            R = 64
+            while R > 1 and R * C * 4 > 64 * 1024:
+                R >>= 1
+            q_magic = ((1 << 24) + Q - 1) // Q
+            j = np.arange(R * Q, dtype=np.uint64)
+            assert int(j[-1]) * q_magic < 2 ** 32, (d, L, R)
+            assert np.array_equal((j * np.uint64(q_magic)) >> np.uint64(24), j // np.uint64(Q)), (d, L, R)
+            pslot = np.arange(max(d * L, 1), dtype=np.uint64)
+            assert int(pslot[-1]) * d_magic < 2 ** 32
+            assert np.array_equal((pslot * np.uint64(d_magic)) >> np.uint64(24), pslot // np.uint64(d)), (d, L)
