@@ -85,12 +85,12 @@ def run_satellites(dev, reps=20, only=None, quiet=False):
             lambda: _lib.check(L.swnerf_pack_ray_batch(p(ro), p(rd), n, 2., 6., 1, .5, 0, 800, 800, 1111., p(rb), st()), "pack"), n * (24 + 48))
         del ro, rd, rb
     # ---- embed (a6): the C2 fine pass's rows
-    M = 786432
-    for d, Lb in ((3, 10), (3, 4), (1, 10)):
+    for M, d, Lb in ((786432, 3, 10), (786432, 3, 4), (786432, 1, 10), (8388608, 3, 10), (8388608, 1, 10)):   # ... and sizes where launch ramp no longer shows
         x = rnd(M, d) * 12 - 6
         C = d * (1 + 2 * Lb)
         out = torch.empty((M, C), device=dev)
         run(f"embed {M} x {d} -> {C} (L={Lb})", "embed_kernel", lambda: _lib.check(L.swnerf_embed(p(x), M, d, Lb, p(out), st()), "embed"), M * 4 * (d + C), EMB)
+        del x, out
     # ---- raw2outputs (a10) forward / backward on the 800x800 frame at S = 192 (and S = 64)
     for S in (192, 64):
         N = 640000
