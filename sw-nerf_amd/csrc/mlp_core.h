@@ -573,7 +573,9 @@ __device__ __forceinline__ void canon_tail_train(const f32x16 (&in)[8], const fl
     for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[n][r] = relu1(hv[n][r]);
+#ifndef TRAIN_EXP_NOBURST                               // (timing experiment: tools/experiments/train/build.sh)
     tiles_store<4>(act_row + SW_ACT_HV, hv);
+#endif
     *reinterpret_cast<f32x4*>(mask_tile + 256 * 8) = relu_bits<4>(hv);
     head_valu<3, 4>(hv, ws, rgb);
     rgb[0] += hb_rgb[1]; rgb[1] += hb_rgb[2]; rgb[2] += hb_rgb[3];

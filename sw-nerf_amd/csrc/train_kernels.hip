@@ -4,7 +4,9 @@
 // a store's write acknowledge takes longer than 6 ring steps often enough to cost 8 % (measured: forward 7.57 ->
 // 6.94 ms, dX chain 6.64 -> 6.32 ms at 786 k rows).  The render kernels keep 8: their LDS also holds 28 KB of
 // resampling scratch, and depth made no difference there.
+#ifndef SW_RING
 #define SW_RING 16
+#endif
 #include "mlp_kernels.h"
 #include "render_pass.h"
 
